@@ -1,0 +1,116 @@
+// cone_common.h — types shared by the HIP kernels and the serial test build.
+//
+// Everything in csrc/ is written once against a small "SPMD context" (Ctx)
+// interface: the HIP build instantiates it with one 64-lane wavefront per
+// training instance (ctx_wave.h); tests/emul instantiates it with a single
+// serial lane so the identical control flow can be run under gcc + ASan/UBSan
+// on a machine without a GPU.  The serial build is test infrastructure only —
+// the Python package never loads it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CAVE_HD __device__ __forceinline__
+#else
+#define CAVE_HD inline
+#endif
+
+namespace cave {
+
+// per-instance status codes (also in include/cave_hip.h)
+enum : int32_t {
+  ST_OK = 0,
+  ST_NOT_CONVERGED = 1,  // Newton iteration cap hit (SciPy: RuntimeError, src/cave.py:307)
+  ST_TOO_LARGE = 2,      // cone does not fit the LDS arena / nnz_cap / PMAX of this launch
+  ST_BAD_INPUT = 3,      // non-finite input
+};
+
+// operating modes of the fused per-instance kernel
+enum : int32_t {
+  MODE_PROJECT = 0,    // _batch_project(..., 'nnls')            src/cave.py:231-264,298-309
+  MODE_EXACT = 1,      // exactConeAlignedCosine fwd+bwd          src/cave.py:55-73,121-129
+  MODE_INNER = 2,      // innerConeAlignedCosine QP branch (nnls) src/cave.py:206-219
+  MODE_HEURISTIC = 3,  // innerConeAlignedCosine heuristic branch src/cave.py:201-204
+  MODE_AVG = 4,        // _average_ctrs only                      src/cave.py:222-228
+};
+
+// reference thresholds
+static constexpr float kDropRowAbsSum = 1e-7f;  // src/cave.py:303
+static constexpr float kAvgRowNorm = 1e-7f;     // src/cave.py:225
+static constexpr double kNormClamp = 1e-8;      // src/cave.py:129,202,226 and F.cosine_similarity eps
+static constexpr float kInsideRnorm = 1e-7f;    // src/cave.py:218
+
+// row tags produced by classification
+enum : uint8_t { ROW_DROP = 0, ROW_UNIT = 1, ROW_GENERAL = 2, ROW_AVG_VALID = 0x10 };
+
+// Bump allocator over one LDS (or heap) buffer.  All lanes run it uniformly.
+struct Arena {
+  unsigned char* base;
+  uint32_t off;
+  uint32_t cap;
+  bool ovf;
+  CAVE_HD void init(unsigned char* b, uint32_t c) { base = b; off = 0; cap = c; ovf = false; }
+  template <class T>
+  CAVE_HD T* get(uint32_t n) {
+    uint32_t a = (off + 7u) & ~7u;
+    uint64_t e = (uint64_t)a + (uint64_t)n * sizeof(T);
+    if (e > cap) { ovf = true; return reinterpret_cast<T*>(base); }
+    off = (uint32_t)e;
+    return reinterpret_cast<T*>(base + a);
+  }
+};
+
+// What the Newton solver needs to know about one cone (all pointers LDS-resident).
+struct SolveView {
+  int d;                  // cost dimension
+  int p;                  // reduced unknowns: one per general row (a +a/-a pair counts once)
+  int n_valid;            // rows kept by the projection (0 -> empty cone -> proj = y)
+  const uint32_t* mlo;    // [p]  CSR row begin of reduced row i in (ecol, eval)
+  const uint32_t* mhi;    // [p]  CSR row end
+  const uint16_t* ecol;
+  const float* eval;
+  const uint8_t* vkind;   // [p]  1 = free multiplier (paired row), 0 = non-negative
+  const uint32_t* cptr;   // [d+1] CSC of the reduced rows
+  const uint16_t* cvar;
+  const float* cvalc;
+  const uint8_t* usign;   // [d]  bit0: +e_k row present, bit1: -e_k row present
+};
+
+struct SolveWork {
+  float* y;        // [d]
+  double* res;     // [d]  residual y - M^T theta (unclipped while iterating, clipped on return)
+  double* q;       // [d]  M^T (search direction)
+  double* theta;   // [p]
+  double* ttry;    // [p]
+  double* g;       // [p]
+  double* dv;      // [p]  model gradient in the inner loop, then the search direction
+  double* g2;      // [p]  right-hand side / H*step scratch
+  double* step;    // [p]  Newton step of one inner round
+  double* H;       // [p*ldh]
+  uint8_t* act;    // [p]
+  int ldh;
+};
+
+struct SolveResult {
+  double f;        // 0.5*||res||^2
+  int iters;
+  int32_t status;
+};
+
+// 64-bit mix for row hashing (pair detection)
+CAVE_HD uint64_t mix64(uint64_t h, uint64_t v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 32;
+  return h;
+}
+
+CAVE_HD uint32_t f2u(float f) {
+  union { float f; uint32_t u; } x;
+  x.f = f;
+  return x.u;
+}
+
+}  // namespace cave

@@ -1,0 +1,555 @@
+// cone_core.h — per-instance cone projection, written once against a Ctx.
+//
+// Replaces, for one training instance, the work of
+//   _project_nnls        (/root/reference  src/cave.py:298-309)
+//   _average_ctrs        (src/cave.py:222-228)
+//   the loss / target algebra of forward() and _get_projection()
+//                        (src/cave.py:55-73,121-129,197-219)
+//
+// Algorithm (not the reference's Lawson-Hanson):
+//   rows of A are split into signed-unit rows (c*e_k), +a/-a pairs (free
+//   multiplier) and remaining "general" rows (non-negative multiplier).  With
+//   M the reduced rows and Pi the coordinate-wise clip induced by the unit
+//   rows, the projection residual is res* = Pi(y - M^T theta*) where theta*
+//   minimises the C^1 piecewise-quadratic
+//        f(theta) = 1/2 || Pi(y - M^T theta) ||^2 ,  theta_i >= 0 for unpaired rows
+//   which is solved by a projected semismooth Newton method in fp64
+//   (generalised Hessian M D M^T, Bertsekas epsilon-active set, Armijo
+//   backtracking on the projection arc).  proj = y - res*, rnorm = ||res*||_2.
+#pragma once
+#include "cone_common.h"
+
+namespace cave {
+
+// ------------------------------------------------------------------ cone build
+
+struct ConeBuild {
+  int d, m;
+  uint32_t nnz_all;  // non-zeros of the whole instance (row-major order)
+  uint16_t* ecol;    // [nnz_cap]
+  float* eval;       // [nnz_cap]
+  uint32_t* rptr;    // [m+1]
+  uint32_t* ucnt;    // [d] low 16 bits: number of +e_k rows, high 16 bits: number of -e_k rows
+  uint8_t* usign;    // [d]
+  uint8_t* rowtag;   // [m]
+  uint32_t* vraw;    // [p_raw] general rows, in row order (both twins of a pair)
+  float* vnorm;      // [p_raw] l2 norm of those rows
+  int p_raw;
+  uint32_t* mlo;     // [p]
+  uint32_t* mhi;     // [p]
+  uint8_t* vkind;    // [p]
+  int p;
+  uint32_t nnzM;
+  uint32_t* cptr;    // [d+1]
+  uint16_t* cvar;    // [nnzM]
+  float* cvalc;      // [nnzM]
+  int n_valid_proj;
+  int n_valid_avg;
+};
+
+// Classify rows, detect +a/-a pairs, build CSR/CSC of the reduced rows.
+// Pre: cb.ecol/eval/rptr hold the scan output (rptr = per-row counts, m+1 entries,
+// last = 0), cb.nnz_all set.  Returns ST_OK or ST_TOO_LARGE.
+template <class C>
+CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
+  const int d = cb.d, m = cb.m;
+  const int NT = C::NT;
+  // 1. row counts -> row pointers
+  c.exclusive_scan_u32(cb.rptr, m + 1);
+  cb.ucnt = ar.get<uint32_t>(d);
+  cb.usign = ar.get<uint8_t>(d);
+  cb.rowtag = ar.get<uint8_t>(m > 0 ? m : 1);
+  if (ar.ovf) return ST_TOO_LARGE;
+  for (int k = c.tid(); k < d; k += NT) cb.ucnt[k] = 0;
+  c.sync();
+  // 2. per-row statistics and tags
+  uint32_t nvp = 0, nva = 0, ngen = 0;
+  for (int r = c.tid(); r < m; r += NT) {
+    uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (uint32_t e = lo; e < hi; ++e) {
+      float v = cb.eval[e];
+      s1 += fabsf(v);
+      s2 += v * v;
+    }
+    uint8_t tag = ROW_DROP;
+    if (s1 > kDropRowAbsSum) {  // src/cave.py:303
+      nvp++;
+      if (hi - lo == 1) {
+        tag = ROW_UNIT;
+        uint16_t col = cb.ecol[lo];
+        c.atomic_add_u32(&cb.ucnt[col], cb.eval[lo] > 0.f ? 1u : 0x10000u);
+      } else {
+        tag = ROW_GENERAL;
+        ngen++;
+      }
+      if (sqrtf(s2) > kAvgRowNorm) { tag |= ROW_AVG_VALID; nva++; }  // src/cave.py:224-225
+    }
+    cb.rowtag[r] = tag;
+  }
+  cb.n_valid_proj = (int)c.reduce_add_u32(nvp);
+  cb.n_valid_avg = (int)c.reduce_add_u32(nva);
+  cb.p_raw = (int)c.reduce_add_u32(ngen);
+  c.sync();
+  for (int k = c.tid(); k < d; k += NT)
+    cb.usign[k] = (uint8_t)(((cb.ucnt[k] & 0xffffu) ? 1 : 0) | ((cb.ucnt[k] >> 16) ? 2 : 0));
+  // 3. ordered list of general rows
+  const int pr = cb.p_raw;
+  cb.vraw = ar.get<uint32_t>(pr > 0 ? pr : 1);
+  cb.vnorm = ar.get<float>(pr > 0 ? pr : 1);
+  uint32_t* twin = ar.get<uint32_t>(pr > 0 ? pr : 1);
+  uint8_t* keep = ar.get<uint8_t>(pr > 0 ? pr : 1);
+  cb.mlo = ar.get<uint32_t>(pr > 0 ? pr : 1);
+  cb.mhi = ar.get<uint32_t>(pr > 0 ? pr : 1);
+  cb.vkind = ar.get<uint8_t>(pr > 0 ? pr : 1);
+  cb.cptr = ar.get<uint32_t>(d + 1);
+  if (ar.ovf) return ST_TOO_LARGE;
+  c.compact_mask_u8(cb.rowtag, m, 0x0F, ROW_GENERAL, cb.vraw);
+  c.sync();
+  // 4. pair detection by (hash(+a), hash(-a)); hashes live in scratch carved after
+  //    the persistent arrays and released again below.
+  const uint32_t arena_mark = ar.off;
+  uint64_t* hp = ar.get<uint64_t>(pr > 0 ? pr : 1);
+  uint64_t* hn = ar.get<uint64_t>(pr > 0 ? pr : 1);
+  if (ar.ovf) return ST_TOO_LARGE;
+  for (int i = c.tid(); i < pr; i += NT) {
+    uint32_t r = cb.vraw[i];
+    uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+    uint64_t a = 0x1234567ull, b = 0x1234567ull;
+    float s2 = 0.f;
+    for (uint32_t e = lo; e < hi; ++e) {
+      uint32_t u = f2u(cb.eval[e]);
+      uint64_t col = cb.ecol[e];
+      a = mix64(a, (col << 32) | u);
+      b = mix64(b, (col << 32) | (u ^ 0x80000000u));
+      s2 += cb.eval[e] * cb.eval[e];
+    }
+    hp[i] = a;
+    hn[i] = b;
+    cb.vnorm[i] = sqrtf(s2);
+  }
+  c.sync();
+  for (int i = c.tid(); i < pr; i += NT) {
+    uint64_t a = hp[i], b = hn[i];
+    int same = 0, opp = 0;
+    uint32_t cand = 0xffffffffu;
+    for (int j = 0; j < pr; ++j) {
+      uint64_t hj = hp[j];
+      same += (hj == a);
+      if (hj == b) { opp++; if (cand == 0xffffffffu) cand = (uint32_t)j; }
+    }
+    uint32_t t = 0xffffffffu;
+    if (same == 1 && opp == 1) {
+      // exact verification: same columns, negated values
+      uint32_t r = cb.vraw[i], q = cb.vraw[cand];
+      uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+      uint32_t lo2 = cb.rptr[q], hi2 = cb.rptr[q + 1];
+      bool ok = (hi - lo) == (hi2 - lo2);
+      for (uint32_t e = 0; ok && e < hi - lo; ++e)
+        ok = (cb.ecol[lo + e] == cb.ecol[lo2 + e]) && (cb.eval[lo + e] == -cb.eval[lo2 + e]);
+      if (ok) t = cand;
+    }
+    twin[i] = t;
+  }
+  c.sync();
+  for (int i = c.tid(); i < pr; i += NT) {
+    uint32_t t = twin[i];
+    bool paired = (t != 0xffffffffu) && (twin[t] == (uint32_t)i);
+    // keep the lower-indexed twin as the free variable, drop the other
+    keep[i] = (uint8_t)((paired && t < (uint32_t)i) ? 0 : (paired ? 2 : 1));
+  }
+  c.sync();
+  ar.off = arena_mark;  // release hash scratch
+  // 5. reduced variable list (ordered): reuse twin[] as the compacted index list
+  uint32_t* vidx = twin;  // overwritten below only after keep[] has been fully derived
+  cb.p = (int)c.compact_nonzero_u8(keep, pr, vidx);
+  c.sync();
+  const int p = cb.p;
+  uint32_t nnzM_local = 0;
+  for (int i = c.tid(); i < p; i += NT) {
+    uint32_t src = vidx[i];
+    uint32_t r = cb.vraw[src];
+    cb.mlo[i] = cb.rptr[r];
+    cb.mhi[i] = cb.rptr[r + 1];
+    cb.vkind[i] = (uint8_t)(keep[src] == 2 ? 1 : 0);
+    nnzM_local += cb.rptr[r + 1] - cb.rptr[r];
+  }
+  cb.nnzM = c.reduce_add_u32(nnzM_local);
+  c.sync();
+  // 6. CSC of the reduced rows
+  cb.cvar = ar.get<uint16_t>(cb.nnzM > 0 ? cb.nnzM : 1);
+  cb.cvalc = ar.get<float>(cb.nnzM > 0 ? cb.nnzM : 1);
+  const uint32_t mark2 = ar.off;
+  uint32_t* fill = ar.get<uint32_t>(d);
+  if (ar.ovf) return ST_TOO_LARGE;
+  for (int k = c.tid(); k <= d; k += NT) cb.cptr[k] = 0;
+  for (int k = c.tid(); k < d; k += NT) fill[k] = 0;
+  c.sync();
+  for (int i = c.tid(); i < p; i += NT)
+    for (uint32_t e = cb.mlo[i]; e < cb.mhi[i]; ++e) c.atomic_add_u32(&cb.cptr[cb.ecol[e]], 1u);
+  c.sync();
+  c.exclusive_scan_u32(cb.cptr, d + 1);
+  c.sync();
+  for (int i = 0; i < p; ++i) {  // rows in order -> entries of a column sorted by variable
+    uint32_t lo = cb.mlo[i], hi = cb.mhi[i];
+    for (uint32_t e = lo + c.tid(); e < hi; e += NT) {
+      uint16_t col = cb.ecol[e];
+      uint32_t pos = cb.cptr[col] + fill[col];
+      fill[col] += 1;  // columns within one row are distinct: no conflict
+      cb.cvar[pos] = (uint16_t)i;
+      cb.cvalc[pos] = cb.eval[e];
+    }
+    c.sync();
+  }
+  ar.off = mark2;  // release fill[]
+  return ST_OK;
+}
+
+// Per-instance average of unit-normalised valid rows (src/cave.py:222-228).
+template <class C>
+CAVE_HD void compute_avg(C& c, const ConeBuild& cb, float* avg) {
+  const int NT = C::NT;
+  for (int k = c.tid(); k < cb.d; k += NT) avg[k] = (float)(cb.ucnt[k] & 0xffffu) - (float)(cb.ucnt[k] >> 16);
+  c.sync();
+  for (int i = 0; i < cb.p_raw; ++i) {
+    uint32_t r = cb.vraw[i];
+    if (!(cb.rowtag[r] & ROW_AVG_VALID)) continue;  // uniform
+    float inv = 1.0f / fmaxf(cb.vnorm[i], (float)kNormClamp);
+    for (uint32_t e = cb.rptr[r] + c.tid(); e < cb.rptr[r + 1]; e += NT) avg[cb.ecol[e]] += cb.eval[e] * inv;
+    c.sync();
+  }
+  float invn = 1.0f / (float)(cb.n_valid_avg > 1 ? cb.n_valid_avg : 1);
+  for (int k = c.tid(); k < cb.d; k += NT) avg[k] *= invn;
+  c.sync();
+}
+
+// --------------------------------------------------------------------- solver
+
+CAVE_HD double clip_unit(double r, uint8_t u) {
+  // residual left after the best multipliers of the +e_k / -e_k rows (closed form)
+  if (u == 3) return 0.0;
+  if (u == 1) return fmin(r, 0.0);
+  if (u == 2) return fmax(r, 0.0);
+  return r;
+}
+
+// out[k] = base[k] - (M^T th)[k]   (base = y, or null for 0);  one CSC gather pass
+template <class C>
+CAVE_HD void gather_mt(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
+  for (int k = c.tid(); k < v.d; k += C::NT) {
+    double r = base ? (double)base[k] : 0.0;
+    for (uint32_t e = v.cptr[k]; e < v.cptr[k + 1]; ++e) r += sgn * (double)v.cvalc[e] * th[v.cvar[e]];
+    out[k] = r;
+  }
+  c.sync();
+}
+
+// 1/2 || Pi(r) ||^2
+template <class C>
+CAVE_HD double half_sq_clipped(C& c, const SolveView& v, const double* r) {
+  double acc = 0.0;
+  for (int k = c.tid(); k < v.d; k += C::NT) {
+    double t = clip_unit(r[k], v.usign[k]);
+    acc += t * t;
+  }
+  return 0.5 * c.reduce_sum(acc);
+}
+
+// phi'(alpha) and phi''(alpha) of phi(alpha) = 1/2 || Pi(r - alpha q) ||^2
+template <class C>
+CAVE_HD void dphi(C& c, const SolveView& v, const double* r, const double* q, double alpha, double* d1, double* d2) {
+  double a1 = 0.0, a2 = 0.0;
+  for (int k = c.tid(); k < v.d; k += C::NT) {
+    double qk = q[k];
+    double t = clip_unit(r[k] - alpha * qk, v.usign[k]);
+    if (t != 0.0) { a1 -= t * qk; a2 += qk * qk; }
+  }
+  *d1 = c.reduce_sum(a1);
+  *d2 = c.reduce_sum(a2);
+}
+
+// One Newton step = exact minimisation of the local quadratic model over the
+// non-negativity constraints by a primal active-set inner loop (ratio test to
+// the first blocking bound, fix it at zero, re-solve on the smaller face — the
+// inner loop of Lawson-Hanson applied to the model), followed by an EXACT line
+// search on the true piecewise-quadratic f along the feasible segment (and
+// beyond it while no bound blocks): phi' is monotone piecewise-linear, so a
+// safeguarded 1-D Newton iteration finds its root in a few O(d) passes.
+// Iterates stay feasible, bound variables sit at exactly 0, and for a pure
+// quadratic (no unit rows) the outer loop is a block active-set NNLS method.
+//
+// On return w.res holds the CLIPPED residual Pi(y - M^T theta).
+template <class C>
+CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
+  const int NT = C::NT;
+  const int p = v.p, d = v.d;
+  SolveResult out;
+  out.iters = 0;
+  out.status = ST_OK;
+  double* theta = w.theta;
+  double* tc = w.ttry;  // working point of the inner loop
+  double* r = w.res;    // UNCLIPPED residual y - M^T theta during the iteration
+  for (int i = c.tid(); i < p; i += NT) theta[i] = 0.0;
+  double yy = 0.0;
+  for (int k = c.tid(); k < d; k += NT) { yy += (double)w.y[k] * (double)w.y[k]; r[k] = (double)w.y[k]; }
+  yy = c.reduce_sum(yy);
+  c.sync();
+  double f = half_sq_clipped(c, v, r);
+  const int ldh = w.ldh;
+  double g0n = 0.0;
+  double reg_rel = 1e-10;  // Levenberg shift relative to max diag(H); raised when a step stalls
+  bool converged = (p == 0);
+  int it = 0;
+  for (; p > 0 && it < max_iter; ++it) {
+    // gradient g = -M Pi(r) and projected-gradient norm
+    double pgmax = 0.0;
+    for (int i = c.tid(); i < p; i += NT) {
+      double gi = 0.0;
+      for (uint32_t e = v.mlo[i]; e < v.mhi[i]; ++e) {
+        uint16_t col = v.ecol[e];
+        gi -= (double)v.eval[e] * clip_unit(r[col], v.usign[col]);
+      }
+      w.g[i] = gi;
+      double pg = (v.vkind[i] || theta[i] > 0.0) ? gi : fmin(gi, 0.0);
+      pgmax = fmax(pgmax, fabs(pg));
+    }
+    double pgn = c.reduce_max(pgmax);
+    if (it == 0) g0n = pgn;
+#ifdef CAVE_TRACE
+    printf("it %d f %.10e pgn %.6e\n", it, f, pgn);
+#endif
+    if (!(pgn > tol * g0n) || f <= 1e-30 * yy) { converged = true; break; }
+    // generalised Hessian H = M D M^T, D = [Pi(r) != 0], by column outer products
+    for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+    c.sync();
+    for (int k = c.tid(); k < d; k += NT) {
+      if (clip_unit(r[k], v.usign[k]) == 0.0) continue;
+      uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
+      for (uint32_t e1 = lo; e1 < hi; ++e1) {
+        uint32_t a = v.cvar[e1];
+        double va = (double)v.cvalc[e1];
+        c.atomic_add_f64(&w.H[a * ldh + a], va * va);
+        for (uint32_t e2 = lo; e2 < e1; ++e2) {
+          uint32_t b = v.cvar[e2];
+          double vv = va * (double)v.cvalc[e2];
+          c.atomic_add_f64(&w.H[a * ldh + b], vv);
+          c.atomic_add_f64(&w.H[b * ldh + a], vv);
+        }
+      }
+    }
+    c.sync();
+    // ---- model minimisation over theta >= 0 (attempt 0: free every bound variable with
+    //      a negative multiplier; attempt 1, only if that made no move: free the most negative one)
+    bool moved = false;
+    for (int attempt = 0; attempt < 2 && !moved; ++attempt) {
+      double gmin = 0.0;
+      if (attempt == 1) {
+        double gl = 0.0;
+        for (int i = c.tid(); i < p; i += NT)
+          if (!v.vkind[i] && theta[i] <= 0.0) gl = fmin(gl, w.g[i]);
+        gmin = -c.reduce_max(-gl);
+        if (!(gmin < 0.0)) break;
+      }
+      for (int i = c.tid(); i < p; i += NT) {
+        bool at_bound = !v.vkind[i] && theta[i] <= 0.0;
+        bool release = attempt == 0 ? (w.g[i] < 0.0) : (w.g[i] <= gmin);
+        w.act[i] = (uint8_t)((at_bound && !release) ? 1 : 0);
+        tc[i] = theta[i];
+        w.dv[i] = w.g[i];  // dv doubles as the model gradient at tc
+      }
+      c.sync();
+      for (int inner = 0; inner <= p; ++inner) {
+        // rhs: -model gradient on free rows, "go to zero" on fixed rows
+        double* rhs = w.g2;
+        for (int i = c.tid(); i < p; i += NT) rhs[i] = w.act[i] ? -tc[i] : -w.dv[i];
+        c.sync();
+        c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
+        c.sync();
+        // ratio test to the first blocking bound
+        double amin = 2.0;
+        for (int i = c.tid(); i < p; i += NT) {
+          if (!v.vkind[i] && !w.act[i]) {
+            double t = tc[i] + w.step[i];
+            if (t < 0.0) amin = fmin(amin, tc[i] / (tc[i] - t));
+          }
+        }
+        amin = -c.reduce_max(-amin);
+        const bool blocked = amin < 1.0;
+        const double a = blocked ? fmax(amin, 0.0) : 1.0;
+        // model gradient update  gm += a * H step   (before tc/act change)
+        for (int i = c.tid(); i < p; i += NT) {
+          double s = 0.0;
+          for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
+          rhs[i] = s;  // rhs is dead until the next inner round
+        }
+        c.sync();
+        for (int i = c.tid(); i < p; i += NT) {
+          double t = tc[i] + w.step[i];
+          double tn = tc[i] + a * w.step[i];
+          if (!v.vkind[i] && !w.act[i] && blocked && t < 0.0 && tc[i] <= a * (tc[i] - t) * (1.0 + 1e-12)) {
+            tn = 0.0;
+            w.act[i] = 1;
+          }
+          if (w.act[i]) tn = 0.0;
+          tc[i] = tn;
+          w.dv[i] += a * rhs[i];
+        }
+        c.sync();
+        if (!blocked) break;
+      }
+      double mv = 0.0;
+      for (int i = c.tid(); i < p; i += NT) mv = fmax(mv, fabs(tc[i] - theta[i]));
+      moved = c.reduce_max(mv) > 0.0;
+    }
+    if (!moved) { converged = !(pgn > 1e-6 * g0n); break; }
+    // ---- exact line search on the true f along dv = tc - theta
+    double psi0 = 0.0, amax = 1e300;
+    for (int i = c.tid(); i < p; i += NT) {
+      double di = tc[i] - theta[i];
+      w.dv[i] = di;
+      psi0 += w.g[i] * di;
+      if (!v.vkind[i] && di < 0.0) amax = fmin(amax, theta[i] / (-di));
+    }
+    psi0 = c.reduce_sum(psi0);
+    amax = -c.reduce_max(-amax);  // >= 1 because tc is feasible
+    if (amax < 1.0) amax = 1.0;
+    c.sync();
+    if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n); break; }
+    gather_mt(c, v, nullptr, w.dv, 1.0, w.q);  // q = M^T dv, so r(alpha) = r - alpha q
+    double alpha = 1.0, lo = 0.0, hi = amax;
+    double d1, d2;
+    const double psitol = 1e-12 * fabs(psi0);
+    for (int ls = 0; ls < 60; ++ls) {
+      dphi(c, v, r, w.q, alpha, &d1, &d2);
+#ifdef CAVE_TRACE
+      printf("   ls %d alpha %.6e psi %.3e (psi0 %.3e) curv %.3e  [%g, %g]\n", ls, alpha, d1, psi0, d2, lo, hi);
+#endif
+      if (fabs(d1) <= psitol) break;
+      if (d1 < 0.0) {
+        lo = alpha;
+        if (alpha >= amax) break;  // a bound blocks: stay at the end of the segment
+      } else hi = alpha;
+      double an = (d2 > 0.0) ? alpha - d1 / d2 : (d1 < 0.0 ? 2.0 * alpha : 0.5 * (lo + alpha));
+      if (hi < 1e299) { if (!(an > lo && an < hi)) an = 0.5 * (lo + hi); }
+      else if (!(an > lo)) an = 2.0 * alpha;
+      if (an > amax) an = amax;
+      if (hi - lo <= 1e-15 * hi) break;
+      alpha = an;
+    }
+    for (int i = c.tid(); i < p; i += NT) {
+      double t = theta[i] + alpha * w.dv[i];
+      if (!v.vkind[i]) {
+        // variables the inner loop parked at a bound, or that block the extended step, sit at exactly 0
+        if ((alpha == 1.0 && tc[i] == 0.0) || t < 0.0 || (alpha >= amax && w.dv[i] < 0.0 && theta[i] <= -amax * w.dv[i] * (1.0 + 1e-12))) t = 0.0;
+      }
+      theta[i] = t;
+    }
+    c.sync();
+    gather_mt(c, v, w.y, theta, -1.0, r);  // fresh residual (no drift)
+    double fn = half_sq_clipped(c, v, r);
+    // An exact line search along the Newton direction that no longer lowers f beyond
+    // round-off means the Newton decrement is ~0: by the projection inequality
+    // ||proj - proj*||^2 <= 2 (f - f*), so this is fp32-exact long before it triggers.
+    const bool tiny_gain = !(f - fn > 1e-15 * f);
+    f = fn;
+    if (tiny_gain) {
+      // Either we are done (projected gradient at round-off level), or the Newton direction
+      // was dominated by a (near-)null direction of a rank-deficient Hessian: damp harder,
+      // which turns the step towards steepest descent, and go on.
+      if (!(pgn > 1e-8 * g0n)) { converged = true; ++it; break; }
+      if (reg_rel >= 1e-2) { converged = false; ++it; break; }
+      reg_rel *= 1e3;
+    } else if (reg_rel > 1e-10) reg_rel *= 0.1;
+  }
+  // leave the clipped residual behind for the epilogue
+  for (int k = c.tid(); k < d; k += NT) r[k] = clip_unit(r[k], v.usign[k]);
+  c.sync();
+  if (!converged) out.status = ST_NOT_CONVERGED;
+  if (!(f == f) || !(yy == yy)) out.status = ST_BAD_INPUT;
+  out.f = f;
+  out.iters = it;
+  return out;
+}
+
+// ------------------------------------------------------------------- epilogue
+
+struct EpilogueOut {
+  float* proj;    // [d] or null
+  float* rnorm;   // scalar or null
+  float* target;  // [d] or null
+  float* loss;    // scalar or null
+  float* grad;    // [d] or null   d loss_i / d pred
+};
+
+// y = sign*pred (LDS, float); res = clipped residual (fp64) or null when the
+// projection was skipped (heuristic); avg = per-instance average normal or null.
+// tvec: LDS scratch [d] doubles for the target.
+template <class C>
+CAVE_HD void epilogue(C& c, int mode, int d, float sign, float inner_ratio, bool empty_cone,
+                      const float* y, const double* res, double f, const float* avg, double* tvec,
+                      const EpilogueOut& o) {
+  const int NT = C::NT;
+  if (mode == MODE_AVG) {
+    if (o.target) for (int k = c.tid(); k < d; k += NT) o.target[k] = avg[k];
+    return;
+  }
+  const bool has_proj = (mode != MODE_HEURISTIC);
+  float rn = 0.f;
+  double pp = 0.0, ss = 0.0;
+  for (int k = c.tid(); k < d; k += NT) {
+    double yk = (double)y[k];
+    ss += yk * yk;
+    if (has_proj) {
+      // empty cone: reference returns cp itself (src/cave.py:304-305)
+      float pk = empty_cone ? y[k] : (float)(yk - res[k]);
+      if (o.proj) o.proj[k] = pk;
+      tvec[k] = (double)pk;
+      pp += (double)pk * (double)pk;
+    }
+  }
+  pp = c.reduce_sum(pp);
+  ss = c.reduce_sum(ss);
+  if (has_proj) {
+    rn = empty_cone ? 0.f : (float)sqrt(2.0 * f);
+    if (o.rnorm && c.tid() == 0) *o.rnorm = rn;
+  }
+  if (mode == MODE_PROJECT) return;
+  c.sync();
+  const double ns = sqrt(ss);
+  const double ns_c = fmax(ns, kNormClamp);
+  // target vector
+  double tt = 0.0, st = 0.0;
+  const double r = (double)inner_ratio;
+  const double np_c = fmax(sqrt(pp), kNormClamp);
+  const bool inside = rn < kInsideRnorm;  // src/cave.py:218
+  for (int k = c.tid(); k < d; k += NT) {
+    double t;
+    if (mode == MODE_EXACT) t = tvec[k] / np_c;                                  // :129
+    else if (mode == MODE_INNER) {
+      double pn = tvec[k] / np_c;                                                // :211
+      t = inside ? pn : (1.0 - r) * pn + r * (double)avg[k];                      // :216-219
+    } else t = (1.0 - r) * ((double)y[k] / ns_c) + r * (double)avg[k];           // :202-204
+    t = (double)(float)t;  // the reference target is a float32 tensor
+    tvec[k] = t;
+    tt += t * t;
+    st += (double)y[k] * t;
+  }
+  tt = c.reduce_sum(tt);
+  st = c.reduce_sum(st);
+  c.sync();
+  const double nt_c = fmax(sqrt(tt), kNormClamp);
+  // F.cosine_similarity: sum_k (x/max(|x|,eps))_k (t/max(|t|,eps))_k  (src/cave.py:72)
+  const double cosv = st / (ns_c * nt_c);
+  if (o.loss && c.tid() == 0) *o.loss = (float)(1.0 - cosv);
+  const double inv = 1.0 / (ns_c * nt_c);
+  const double radial = (ns > kNormClamp) ? st / (ns_c * ns_c * ns * nt_c) : 0.0;
+  for (int k = c.tid(); k < d; k += NT) {
+    if (o.target) o.target[k] = (float)tvec[k];
+    if (o.grad) {
+      double dcos = tvec[k] * inv - radial * (double)y[k];  // d cos / d signed
+      o.grad[k] = (float)(-(double)sign * dcos);            // loss = 1 - cos, signed = sign*pred
+    }
+  }
+}
+
+}  // namespace cave

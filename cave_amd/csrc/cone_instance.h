@@ -1,0 +1,355 @@
+// cone_instance.h — what one workgroup does for one instance, written against a Ctx.
+// Shared by the HIP kernels (cave_hip.hip, Ctx = WaveCtx) and the serial test
+// build (tests/emul, Ctx = SerialCtx).
+#pragma once
+#include "../../include/cave_hip.h"
+#include "cone_common.h"
+#include "cone_core.h"
+
+namespace cave {
+
+struct OutPtrs {
+  float* proj;
+  float* rnorm;
+  float* target;
+  float* loss;
+  float* grad;
+  int32_t* status;
+  int32_t* iters;
+};
+
+struct DenseParams {
+  const float* ctrs;
+  const float* pred;
+  int64_t B;
+  int32_t m, d;
+  int32_t mode;
+  float sign, inner_ratio;
+  int32_t max_iter;
+  uint32_t nnz_cap, lds_bytes;
+  OutPtrs o;
+};
+
+struct PackParams {
+  const float* ctrs;
+  int64_t B;
+  int32_t m, d;
+  uint32_t nnz_cap, lds_bytes;
+  int32_t* n_rows;
+  int32_t* n_nnz;
+  int32_t* status;
+  cave_cone_store store;  // fill pass only
+  int64_t slot0;
+  int32_t fill;
+};
+
+struct PackedParams {
+  cave_cone_store store;
+  const int64_t* ids;
+  const float* pred;
+  int64_t B;
+  int32_t mode;
+  float sign, inner_ratio;
+  int32_t max_iter;
+  uint32_t lds_bytes;
+  OutPtrs o;
+};
+
+CAVE_HD float quiet_nan() {
+  union { uint32_t u; float f; } x;
+  x.u = 0x7fc00000u;
+  return x.f;
+}
+
+template <class C>
+CAVE_HD void fill_failure(C& c, int d, int64_t b, const OutPtrs& o) {
+  const float nanv = quiet_nan();
+  for (int k = c.tid(); k < d; k += C::NT) {
+    if (o.proj) o.proj[b * d + k] = nanv;
+    if (o.target) o.target[b * d + k] = nanv;
+    if (o.grad) o.grad[b * d + k] = nanv;
+  }
+  if (c.tid() == 0) {
+    if (o.rnorm) o.rnorm[b] = nanv;
+    if (o.loss) o.loss[b] = nanv;
+  }
+}
+
+// scan the dense block + build the reduced cone; returns status
+template <class C>
+CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, int m, int d, uint32_t cap) {
+  cb.d = d;
+  cb.m = m;
+  cb.ecol = ar.get<uint16_t>(cap);
+  cb.eval = ar.get<float>(cap);
+  cb.rptr = ar.get<uint32_t>((uint32_t)m + 1u);
+  if (ar.ovf) return ST_TOO_LARGE;
+  for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
+  c.sync();
+  uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, (uint32_t)d, cb.ecol, cb.eval, cb.rptr, cap);
+  c.sync();
+  if (nnz > cap) return ST_TOO_LARGE;
+  cb.nnz_all = nnz;
+  return build_cone(c, ar, cb);
+}
+
+// Solve + epilogue for one instance whose SolveView is ready.  y must be loaded.
+template <class C>
+CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, float sign, float inner_ratio,
+                                 int max_iter, float* y, const float* avg, int64_t b, const OutPtrs& o,
+                                 int* iters_out) {
+  const int d = v.d;
+  const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER);
+  double* res = ar.get<double>(d);
+  double* tvec = ar.get<double>(d);
+  if (ar.ovf) return ST_TOO_LARGE;
+  int32_t st = ST_OK;
+  double f = 0.0;
+  const bool empty = (v.n_valid == 0);
+  *iters_out = 0;
+  if (need_proj && !empty) {
+    const int p = v.p;
+    if (p > C::PMAX) return ST_TOO_LARGE;
+    SolveWork w;
+    w.y = y;
+    w.res = res;
+    w.q = tvec;  // the epilogue's target scratch is free while the solver runs
+    w.theta = ar.get<double>(p > 0 ? p : 1);
+    w.ttry = ar.get<double>(p > 0 ? p : 1);
+    w.g = ar.get<double>(p > 0 ? p : 1);
+    w.dv = ar.get<double>(p > 0 ? p : 1);
+    w.g2 = ar.get<double>(p > 0 ? p : 1);
+    w.step = ar.get<double>(p > 0 ? p : 1);
+    w.ldh = p | 1;
+    w.H = ar.get<double>((uint32_t)(p > 0 ? p * w.ldh : 1));
+    w.act = ar.get<uint8_t>(p > 0 ? p : 1);
+    if (ar.ovf) return ST_TOO_LARGE;
+    SolveResult r = solve_cone(c, v, w, max_iter, 1e-10);
+    st = r.status;
+    f = r.f;
+    *iters_out = r.iters;
+    if (st == ST_BAD_INPUT) return st;
+  }
+  EpilogueOut eo;
+  eo.proj = o.proj ? o.proj + b * d : nullptr;
+  eo.rnorm = o.rnorm ? o.rnorm + b : nullptr;
+  eo.target = o.target ? o.target + b * d : nullptr;
+  eo.loss = o.loss ? o.loss + b : nullptr;
+  eo.grad = o.grad ? o.grad + b * d : nullptr;
+  epilogue(c, mode, d, sign, inner_ratio, empty, y, res, f, avg, tvec, eo);
+  return st;
+}
+
+template <class C>
+CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P, int64_t b) {
+  const int d = P.d, m = P.m;
+  Arena ar;
+  ar.init(smem, P.lds_bytes);
+  ConeBuild cb;
+  int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
+  int iters = 0;
+  if (st == ST_OK) {
+    const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
+    float* y = ar.get<float>(d);
+    float* avg = need_avg ? ar.get<float>(d) : nullptr;
+    if (ar.ovf) st = ST_TOO_LARGE;
+    else {
+      for (int k = c.tid(); k < d; k += C::NT) y[k] = P.pred ? P.sign * P.pred[b * d + k] : 0.f;
+      c.sync();
+      if (need_avg) compute_avg(c, cb, avg);
+      SolveView v;
+      v.d = d; v.p = cb.p; v.n_valid = cb.n_valid_proj;
+      v.mlo = cb.mlo; v.mhi = cb.mhi; v.ecol = cb.ecol; v.eval = cb.eval; v.vkind = cb.vkind;
+      v.cptr = cb.cptr; v.cvar = cb.cvar; v.cvalc = cb.cvalc; v.usign = cb.usign;
+      st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+    }
+  }
+  if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);
+  if (c.tid() == 0) {
+    if (P.o.status) P.o.status[b] = st;
+    if (P.o.iters) P.o.iters[b] = iters;
+  }
+}
+
+template <class C>
+CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, int64_t b) {
+  const int d = P.d, m = P.m;
+  const int NT = C::NT;
+  Arena ar;
+  ar.init(smem, P.lds_bytes);
+  ConeBuild cb;
+  int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
+  if (!P.fill) {
+    if (c.tid() == 0) {
+      P.n_rows[b] = (st == ST_OK) ? cb.p : 0;
+      P.n_nnz[b] = (st == ST_OK) ? (int32_t)cb.nnzM : 0;
+      if (P.status) P.status[b] = st;
+    }
+    return;
+  }
+  const cave_cone_store& S = P.store;
+  const int64_t slot = P.slot0 + b;
+  float* avg = (st == ST_OK) ? ar.get<float>(d) : nullptr;
+  if (st == ST_OK && ar.ovf) st = ST_TOO_LARGE;
+  if (st == ST_OK) {
+    const int64_t r0 = S.row_off[slot], z0 = S.nnz_off[slot];
+    // the store was sized from pass 1; refuse to write past it
+    if ((int64_t)cb.p != S.row_off[slot + 1] - r0 || (int64_t)cb.nnzM != S.nnz_off[slot + 1] - z0) st = ST_BAD_INPUT;
+    else {
+      compute_avg(c, cb, avg);
+      for (int k = c.tid(); k < d; k += NT) {
+        S.usign[slot * d + k] = cb.usign[k];
+        S.avg[slot * d + k] = avg[k];
+      }
+      for (int k = c.tid(); k <= d; k += NT) S.cptr[slot * (d + 1) + k] = cb.cptr[k];
+      // compact CSR of the reduced rows (rows keep their order)
+      uint32_t run = 0;
+      for (int i = 0; i < cb.p; ++i) {
+        uint32_t lo = cb.mlo[i], hi = cb.mhi[i];
+        for (uint32_t e = lo + c.tid(); e < hi; e += NT) {
+          S.ccol[z0 + run + (e - lo)] = cb.ecol[e];
+          S.cval[z0 + run + (e - lo)] = cb.eval[e];
+        }
+        if (c.tid() == 0) {
+          S.rlo[r0 + i] = run;
+          S.rhi[r0 + i] = run + (hi - lo);
+          S.vkind[r0 + i] = cb.vkind[i];
+        }
+        run += hi - lo;
+      }
+      for (uint32_t e = c.tid(); e < cb.nnzM; e += NT) {
+        S.cvar[z0 + e] = cb.cvar[e];
+        S.cvalc[z0 + e] = cb.cvalc[e];
+      }
+      if (c.tid() == 0) S.n_valid[slot] = cb.n_valid_proj;
+    }
+  }
+  if (c.tid() == 0 && P.status) P.status[b] = st;
+}
+
+template <class C>
+CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& P, int64_t b) {
+  const cave_cone_store& S = P.store;
+  const int d = S.d;
+  const int NT = C::NT;
+  Arena ar;
+  ar.init(smem, P.lds_bytes);
+  const int64_t slot = P.ids ? P.ids[b] : b;
+  int32_t st = ST_OK;
+  int iters = 0;
+  if (slot < 0 || slot >= S.n) st = ST_BAD_INPUT;
+  else {
+    const int64_t r0 = S.row_off[slot], z0 = S.nnz_off[slot];
+    const int p = (int)(S.row_off[slot + 1] - r0);
+    const uint32_t nz = (uint32_t)(S.nnz_off[slot + 1] - z0);
+    const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
+    const bool need_proj = (P.mode == MODE_PROJECT || P.mode == MODE_EXACT || P.mode == MODE_INNER);
+    float* y = ar.get<float>(d);
+    float* avg = need_avg ? ar.get<float>(d) : nullptr;
+    uint8_t* usign = ar.get<uint8_t>(d);
+    uint32_t* cptr = ar.get<uint32_t>(d + 1);
+    uint32_t* mlo = ar.get<uint32_t>(p > 0 ? p : 1);
+    uint32_t* mhi = ar.get<uint32_t>(p > 0 ? p : 1);
+    uint8_t* vkind = ar.get<uint8_t>(p > 0 ? p : 1);
+    uint16_t* ecol = ar.get<uint16_t>(nz > 0 ? nz : 1);
+    float* eval = ar.get<float>(nz > 0 ? nz : 1);
+    uint16_t* cvar = ar.get<uint16_t>(nz > 0 ? nz : 1);
+    float* cvalc = ar.get<float>(nz > 0 ? nz : 1);
+    if (ar.ovf) st = ST_TOO_LARGE;
+    else {
+      for (int k = c.tid(); k < d; k += NT) {
+        y[k] = P.pred ? P.sign * P.pred[b * d + k] : 0.f;
+        usign[k] = S.usign[slot * d + k];
+        if (need_avg) avg[k] = S.avg[slot * d + k];
+      }
+      if (need_proj) {
+        for (int k = c.tid(); k <= d; k += NT) cptr[k] = S.cptr[slot * (d + 1) + k];
+        for (int i = c.tid(); i < p; i += NT) {
+          mlo[i] = S.rlo[r0 + i];
+          mhi[i] = S.rhi[r0 + i];
+          vkind[i] = S.vkind[r0 + i];
+        }
+        for (uint32_t e = c.tid(); e < nz; e += NT) {
+          ecol[e] = S.ccol[z0 + e];
+          eval[e] = S.cval[z0 + e];
+          cvar[e] = S.cvar[z0 + e];
+          cvalc[e] = S.cvalc[z0 + e];
+        }
+      }
+      c.sync();
+      SolveView v;
+      v.d = d; v.p = p; v.n_valid = S.n_valid[slot];
+      v.mlo = mlo; v.mhi = mhi; v.ecol = ecol; v.eval = eval; v.vkind = vkind;
+      v.cptr = cptr; v.cvar = cvar; v.cvalc = cvalc; v.usign = usign;
+      st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+    }
+  }
+  if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);
+  if (c.tid() == 0) {
+    if (P.o.status) P.o.status[b] = st;
+    if (P.o.iters) P.o.iters[b] = iters;
+  }
+}
+
+// ---- arena sizing shared by host code of both builds
+static inline uint32_t align8u(uint64_t x) { return (uint32_t)((x + 7u) & ~7ull); }
+static constexpr uint32_t kMaxLds = 160u * 1024u;
+
+// arena bytes whose size is known from (m, d, cap)
+static inline uint64_t fixed_bytes_dense(int64_t m, int64_t d, int64_t cap) {
+  uint64_t s = 0;
+  s += align8u(2 * cap) + align8u(4 * cap) + align8u(4 * (m + 1));          // ecol, eval, rptr
+  s += align8u(4 * d) + align8u(d) + align8u(m) + align8u(4 * (d + 1));     // ucnt, usign, rowtag, cptr
+  s += align8u(4 * d) * 3 + align8u(8 * d) * 2;                             // fill, y, avg, res, tvec
+  return s + 64;
+}
+
+static inline uint64_t var_bytes(int64_t rows_raw, int64_t p, int64_t nnzM) {
+  uint64_t s = 0;
+  s += 5 * align8u(4 * rows_raw) + 2 * align8u(rows_raw) + 2 * align8u(8 * rows_raw);  // vraw..vkind, hashes
+  s += align8u(2 * nnzM) + align8u(4 * nnzM);                                           // CSC
+  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + align8u(p);                    // theta..step, H, act
+  return s + 64;
+}
+
+static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes) {
+  // structured cones: <= d unit entries + a few sparse rows; dense tiny cones: m*d
+  int64_t cap = 4 * (m_max + d) + 256;
+  if (cap > m_max * d) cap = m_max * d;
+  if (cap < 64) cap = 64;
+  uint64_t need = fixed_bytes_dense(m_max, d, cap) + var_bytes(64, 32, cap * 6 / 10);
+  while (need > kMaxLds && cap > 256) {
+    cap = cap * 3 / 4;
+    need = fixed_bytes_dense(m_max, d, cap) + var_bytes(64, 32, cap * 6 / 10);
+  }
+  if (need > kMaxLds) need = kMaxLds;
+  if (nnz_cap) *nnz_cap = (int32_t)cap;
+  if (lds_bytes) *lds_bytes = (int32_t)need;
+  return 0;
+}
+
+static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& lds) {
+  int32_t dcap = 0, dlds = 0;
+  default_limits(m, d, &dcap, &dlds);
+  if (cap <= 0) cap = dcap;
+  if (lds <= 0) {
+    // honour a caller-supplied nnz_cap when deriving the arena size
+    uint64_t need = fixed_bytes_dense(m, d, cap) + var_bytes(64, 32, (int64_t)cap * 6 / 10);
+    lds = (int32_t)(need > kMaxLds ? kMaxLds : need);
+  }
+  return lds > 0 && (uint32_t)lds <= kMaxLds && cap > 0;
+}
+
+static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz) {
+  uint64_t s = 0;
+  s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
+  s += 2 * align8u(4 * (int64_t)max_rows) + align8u(max_rows);                           // mlo, mhi, vkind
+  s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC
+  s += align8u(8 * d) * 2;                                                               // res, tvec
+  int64_t p = max_rows;
+  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + align8u(p) + 128;
+  if (s > kMaxLds) return -1;
+  return (int32_t)s;
+}
+
+}  // namespace cave

@@ -1,0 +1,147 @@
+/* cave_hip.h — C ABI of the MI355X (gfx950) cone-projection backend for CaVE.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * torch types.  Every pointer is a DEVICE pointer owned by the caller; inputs
+ * are never written; all work is enqueued asynchronously on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream); nothing here
+ * synchronises with the host.  Functions return CAVE_OK or a negative
+ * CAVE_E_* code and never throw; per-instance solver outcomes are data
+ * (`status[B]`, codes CAVE_ST_*), mirroring how the reference reports
+ * Clarabel failures per instance (src/cave.py:293-294) while bad configuration
+ * is rejected up front (src/cave.py:111-117,183-190).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   cave_hip_cone_dense  mode PROJECT   _batch_project(..., solver='nnls') + _project_nnls
+ *                                       src/cave.py:231-264, 298-309
+ *                        mode EXACT     abstractConeAlignedCosine.forward + exact _get_projection
+ *                                       src/cave.py:55-73, 121-129 (and its autograd backward)
+ *                        mode INNER     innerConeAlignedCosine QP branch, nnls push-inside
+ *                                       src/cave.py:206-219
+ *                        mode HEURISTIC innerConeAlignedCosine heuristic branch  src/cave.py:201-204
+ *                        mode AVG       _average_ctrs                            src/cave.py:222-228
+ *   cave_hip_pack_*  / cave_hip_cone_packed
+ *                                       optDatasetConstrs.ctrs storage + collate_fn padding
+ *                                       src/dataset.py:72, 133-144 (device-resident replacement)
+ */
+#ifndef CAVE_HIP_H
+#define CAVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAVE_HIP_ABI_VERSION 1
+
+/* return codes */
+#define CAVE_OK 0
+#define CAVE_E_INVALID (-1)  /* bad argument (null pointer, size out of range) */
+#define CAVE_E_LAUNCH (-2)   /* HIP launch / attribute error, see cave_hip_last_error() */
+#define CAVE_E_NO_DEVICE (-3)
+
+/* per-instance status */
+#define CAVE_ST_OK 0
+#define CAVE_ST_NOT_CONVERGED 1 /* iteration cap reached (SciPy raises RuntimeError, src/cave.py:307) */
+#define CAVE_ST_TOO_LARGE 2     /* cone did not fit this launch's LDS arena; retry with larger limits */
+#define CAVE_ST_BAD_INPUT 3     /* non-finite values */
+
+/* modes */
+#define CAVE_MODE_PROJECT 0
+#define CAVE_MODE_EXACT 1
+#define CAVE_MODE_INNER 2
+#define CAVE_MODE_HEURISTIC 3
+#define CAVE_MODE_AVG 4
+
+int32_t cave_hip_version(void);
+/* thread-local, valid until the next failing call on this thread */
+const char* cave_hip_last_error(void);
+/* number of HIP devices visible (0 if none); does not create a context on failure */
+int32_t cave_hip_device_count(void);
+
+/* Launch limits.  nnz_cap: per-instance capacity for non-zero entries of the
+ * dense block; lds_bytes: dynamic LDS per workgroup (<= 160 KiB).  Pass 0 for
+ * either to let the library choose (cave_hip_default_limits reports the
+ * choice so a caller can grow it after CAVE_ST_TOO_LARGE). */
+int32_t cave_hip_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes);
+
+/* Fused per-instance operator on the reference's dense wire format.
+ *   ctrs  [B, m_max, d] float32 row-major, zero-padded rows  (src/dataset.py:143)
+ *   pred  [B, d]        float32; the kernel works on y = sign * pred
+ *   mode  CAVE_MODE_*;  sign  -1 (EPO.MINIMIZE) / +1 (EPO.MAXIMIZE); for PROJECT pass +1
+ *   inner_ratio  weight of the average normal (INNER, HEURISTIC)
+ *   max_iter     Newton iteration cap (<=0: default 100)
+ * Outputs (any may be NULL):
+ *   proj   [B, d]  projection of y onto cone{lam @ ctrs_b : lam >= 0}
+ *   rnorm  [B]     ||y - proj||_2 (un-squared, nnls convention)
+ *   target [B, d]  the constant target of the cosine loss (unit / pushed / heuristic; AVG: the average)
+ *   loss   [B]     1 - cos(y, target)
+ *   grad   [B, d]  d loss_b / d pred_b
+ *   status [B]     CAVE_ST_*
+ *   iters  [B]     Newton iterations used
+ */
+int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d,
+                            int32_t mode, float sign, float inner_ratio, int32_t max_iter,
+                            int32_t nnz_cap, int32_t lds_bytes,
+                            float* proj, float* rnorm, float* target, float* loss, float* grad,
+                            int32_t* status, int32_t* iters, void* stream);
+
+/* ---- device-resident packed cone store (replaces per-step dense padding) ---- */
+
+/* Pass 1: per instance, count reduced rows and their non-zeros.
+ *   n_rows [B], n_nnz [B], status [B] */
+int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t d,
+                            int32_t nnz_cap, int32_t lds_bytes,
+                            int32_t* n_rows, int32_t* n_nnz, int32_t* status, void* stream);
+
+/* Packed store: structure-of-arrays, all device pointers, filled by cave_hip_pack_fill.
+ *   row_off [n+1], nnz_off [n+1]  exclusive prefix sums of the pass-1 counts (int64)
+ *   n_valid [n]        rows kept by the projection (0 = empty cone)
+ *   usign   [n*d]      bit0: a +e_k row exists, bit1: a -e_k row exists
+ *   avg     [n*d]      _average_ctrs of the instance (static, precomputed)
+ *   vkind   [R]        1 = free multiplier (a +a/-a pair), 0 = non-negative     R = row_off[n]
+ *   rlo,rhi [R]        CSR extent of each reduced row, relative to nnz_off[i]
+ *   ccol, cval [Z]     CSR entries                                              Z = nnz_off[n]
+ *   cptr    [n*(d+1)]  CSC column pointers, relative to nnz_off[i]
+ *   cvar, cvalc [Z]    CSC entries (reduced-row index, value)
+ */
+typedef struct cave_cone_store {
+  int64_t n;
+  int32_t d;
+  int32_t reserved;
+  const int64_t* row_off;
+  const int64_t* nnz_off;
+  int32_t* n_valid;
+  uint8_t* usign;
+  float* avg;
+  uint8_t* vkind;
+  uint32_t* rlo;
+  uint32_t* rhi;
+  uint16_t* ccol;
+  float* cval;
+  uint32_t* cptr;
+  uint16_t* cvar;
+  float* cvalc;
+} cave_cone_store;
+
+/* Pass 2: fill the store for instances [0, B) of `ctrs` at store slots [slot0, slot0+B). */
+int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t d,
+                           int32_t nnz_cap, int32_t lds_bytes,
+                           const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream);
+
+/* Same operator as cave_hip_cone_dense, reading cones from the store:
+ *   ids [B] int64 store slots (the collate_fn replacement hands these out). */
+int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
+                             int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
+                             float* proj, float* rnorm, float* target, float* loss, float* grad,
+                             int32_t* status, int32_t* iters, void* stream);
+
+/* LDS bytes cave_hip_cone_packed needs for the largest instance of a store
+ * (max_rows / max_nnz over instances, from the pass-1 counts). */
+int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAVE_HIP_H */

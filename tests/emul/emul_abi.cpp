@@ -1,0 +1,86 @@
+// emul_abi.cpp — serial gcc build of the per-instance code (TEST INFRASTRUCTURE ONLY).
+// Exports cave_emul_* with the signatures of include/cave_hip.h minus the stream;
+// all pointers are HOST pointers.  Used by tests/ to exercise the shared
+// algorithm code under sanitizers without a GPU; never loaded by cave_amd.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "ctx_serial.h"
+#include "../../cave_amd/csrc/cone_core.h"
+#include "../../cave_amd/csrc/cone_instance.h"
+
+using namespace cave;
+
+extern "C" {
+
+int32_t cave_emul_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes) {
+  return default_limits(m_max, d, nnz_cap, lds_bytes);
+}
+
+int32_t cave_emul_cone_dense(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d, int32_t mode,
+                             float sign, float inner_ratio, int32_t max_iter, int32_t nnz_cap, int32_t lds_bytes,
+                             float* proj, float* rnorm, float* target, float* loss, float* grad, int32_t* status,
+                             int32_t* iters) {
+  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return CAVE_E_INVALID;
+  DenseParams P;
+  P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
+  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
+  P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
+  P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
+  std::vector<unsigned char> smem((size_t)lds_bytes);  // exact size: ASan catches arena overruns
+  SerialCtx c;
+  for (int64_t b = 0; b < B; ++b) run_dense_instance(c, smem.data(), P, b);
+  return CAVE_OK;
+}
+
+int32_t cave_emul_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t d, int32_t nnz_cap,
+                             int32_t lds_bytes, int32_t* n_rows, int32_t* n_nnz, int32_t* status) {
+  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return CAVE_E_INVALID;
+  PackParams P;
+  memset(&P, 0, sizeof(P));
+  P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
+  P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
+  P.n_rows = n_rows; P.n_nnz = n_nnz; P.status = status; P.fill = 0;
+  std::vector<unsigned char> smem((size_t)lds_bytes);
+  SerialCtx c;
+  for (int64_t b = 0; b < B; ++b) run_pack_instance(c, smem.data(), P, b);
+  return CAVE_OK;
+}
+
+int32_t cave_emul_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t d, int32_t nnz_cap,
+                            int32_t lds_bytes, const cave_cone_store* store, int64_t slot0, int32_t* status) {
+  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return CAVE_E_INVALID;
+  if (!store || store->d != d || slot0 < 0 || slot0 + B > store->n) return CAVE_E_INVALID;
+  PackParams P;
+  memset(&P, 0, sizeof(P));
+  P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
+  P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
+  P.status = status; P.store = *store; P.slot0 = slot0; P.fill = 1;
+  std::vector<unsigned char> smem((size_t)lds_bytes);
+  SerialCtx c;
+  for (int64_t b = 0; b < B; ++b) run_pack_instance(c, smem.data(), P, b);
+  return CAVE_OK;
+}
+
+int32_t cave_emul_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz) {
+  int32_t s = packed_lds_bytes(d, max_rows, max_nnz);
+  return s < 0 ? CAVE_E_INVALID : s;
+}
+
+int32_t cave_emul_cone_packed(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
+                              int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
+                              float* proj, float* rnorm, float* target, float* loss, float* grad, int32_t* status,
+                              int32_t* iters) {
+  if (!store || lds_bytes <= 0) return CAVE_E_INVALID;
+  PackedParams P;
+  P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
+  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
+  P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
+  std::vector<unsigned char> smem((size_t)lds_bytes);
+  SerialCtx c;
+  for (int64_t b = 0; b < B; ++b) run_packed_instance(c, smem.data(), P, b);
+  return CAVE_OK;
+}
+
+}  // extern "C"

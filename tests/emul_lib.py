@@ -1,0 +1,119 @@
+"""ctypes loader for the serial gcc build of cave_amd/csrc (TEST INFRASTRUCTURE ONLY).
+
+The build in tests/emul runs the per-instance algorithm code shared with the
+HIP kernels on one serial lane, on host memory.  It exists so the CPU-only test
+tier (and ASan/UBSan) can exercise that code; the cave_amd package never
+imports it.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "emul", "emul_abi.cpp")
+_DEPS = [
+    _SRC,
+    os.path.join(_HERE, "emul", "ctx_serial.h"),
+    os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_core.h"),
+    os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_common.h"),
+    os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_instance.h"),
+    os.path.join(_HERE, "..", "include", "cave_hip.h"),
+]
+
+
+def build(asan: bool = False) -> str:
+    out = os.path.join(_HERE, "emul", "_emul_asan.so" if asan else "_emul.so")
+    newest = max(os.path.getmtime(p) for p in _DEPS)
+    if os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-w", *flags, _SRC, "-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+class Store(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("d", C.c_int32), ("reserved", C.c_int32),
+        ("row_off", C.c_void_p), ("nnz_off", C.c_void_p), ("n_valid", C.c_void_p),
+        ("usign", C.c_void_p), ("avg", C.c_void_p), ("vkind", C.c_void_p),
+        ("rlo", C.c_void_p), ("rhi", C.c_void_p), ("ccol", C.c_void_p), ("cval", C.c_void_p),
+        ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),
+    ]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Emul:
+    def __init__(self, asan: bool = False):
+        self.lib = C.CDLL(build(asan))
+
+    def cone_dense(self, ctrs, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0, nnz_cap=0, lds_bytes=0):
+        ctrs = np.ascontiguousarray(ctrs, dtype=np.float32)
+        B, m, d = ctrs.shape
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        out = {
+            "proj": np.zeros((B, d), np.float32), "rnorm": np.zeros(B, np.float32),
+            "target": np.zeros((B, d), np.float32), "loss": np.zeros(B, np.float32),
+            "grad": np.zeros((B, d), np.float32), "status": np.zeros(B, np.int32),
+            "iters": np.zeros(B, np.int32),
+        }
+        rc = self.lib.cave_emul_cone_dense(
+            _p(ctrs), _p(pred), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int32(mode),
+            C.c_float(sign), C.c_float(inner_ratio), C.c_int32(max_iter), C.c_int32(nnz_cap), C.c_int32(lds_bytes),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
+
+    def pack(self, ctrs, nnz_cap=0, lds_bytes=0):
+        ctrs = np.ascontiguousarray(ctrs, dtype=np.float32)
+        B, m, d = ctrs.shape
+        n_rows = np.zeros(B, np.int32); n_nnz = np.zeros(B, np.int32); status = np.zeros(B, np.int32)
+        rc = self.lib.cave_emul_pack_count(_p(ctrs), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int32(nnz_cap),
+                                           C.c_int32(lds_bytes), _p(n_rows), _p(n_nnz), _p(status))
+        assert rc == 0 and (status == 0).all(), (rc, status)
+        row_off = np.concatenate([[0], np.cumsum(n_rows, dtype=np.int64)]).astype(np.int64)
+        nnz_off = np.concatenate([[0], np.cumsum(n_nnz, dtype=np.int64)]).astype(np.int64)
+        R, Z = int(row_off[-1]), int(nnz_off[-1])
+        arrs = {
+            "row_off": row_off, "nnz_off": nnz_off, "n_valid": np.zeros(B, np.int32),
+            "usign": np.zeros(B * d, np.uint8), "avg": np.zeros(B * d, np.float32),
+            "vkind": np.zeros(max(R, 1), np.uint8), "rlo": np.zeros(max(R, 1), np.uint32),
+            "rhi": np.zeros(max(R, 1), np.uint32), "ccol": np.zeros(max(Z, 1), np.uint16),
+            "cval": np.zeros(max(Z, 1), np.float32), "cptr": np.zeros(B * (d + 1), np.uint32),
+            "cvar": np.zeros(max(Z, 1), np.uint16), "cvalc": np.zeros(max(Z, 1), np.float32),
+        }
+        st = Store(n=B, d=d, reserved=0, **{k: v.ctypes.data for k, v in arrs.items()})
+        rc = self.lib.cave_emul_pack_fill(_p(ctrs), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int32(nnz_cap),
+                                          C.c_int32(lds_bytes), C.byref(st), C.c_int64(0), _p(status))
+        assert rc == 0 and (status == 0).all(), (rc, status)
+        return st, arrs, int(n_rows.max(initial=0)), int(n_nnz.max(initial=0))
+
+    def cone_packed(self, store, arrs, max_rows, max_nnz, ids, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0):
+        d = store.d
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        B = len(ids)
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        lds = self.lib.cave_emul_packed_lds_bytes(C.c_int64(d), C.c_int32(max_rows), C.c_int32(max_nnz))
+        assert lds > 0
+        out = {
+            "proj": np.zeros((B, d), np.float32), "rnorm": np.zeros(B, np.float32),
+            "target": np.zeros((B, d), np.float32), "loss": np.zeros(B, np.float32),
+            "grad": np.zeros((B, d), np.float32), "status": np.zeros(B, np.int32),
+            "iters": np.zeros(B, np.int32),
+        }
+        rc = self.lib.cave_emul_cone_packed(
+            C.byref(store), _p(ids), _p(pred), C.c_int64(B), C.c_int32(mode), C.c_float(sign),
+            C.c_float(inner_ratio), C.c_int32(max_iter), C.c_int32(lds),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
