@@ -1,0 +1,129 @@
+"""ctypes binding of the C ABI in include/cave_hip.h (libcave_hip.so, gfx950).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every call
+passes raw `data_ptr()`s and `torch.cuda.current_stream().cuda_stream` across
+the C boundary.  There is NO CPU fallback: if the shared library is missing or
+no HIP device is visible, `load()` raises ImportError (mirroring how the
+reference refuses solver='clarabel' without cvxpy, src/cave.py:113-117).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libcave_hip.so")
+_SOURCES = [
+    os.path.join(_HERE, "csrc", n)
+    for n in ("cave_hip.hip", "cone_common.h", "cone_core.h", "cone_instance.h", "ctx_wave.h")
+] + [os.path.join(_ROOT, "include", "cave_hip.h")]
+
+# status / mode constants (include/cave_hip.h)
+ST_OK, ST_NOT_CONVERGED, ST_TOO_LARGE, ST_BAD_INPUT = 0, 1, 2, 3
+MODE_PROJECT, MODE_EXACT, MODE_INNER, MODE_HEURISTIC, MODE_AVG = 0, 1, 2, 3, 4
+MAX_LDS = 160 * 1024
+
+ABI_SYMBOLS = (
+    "cave_hip_version", "cave_hip_last_error", "cave_hip_device_count", "cave_hip_default_limits",
+    "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill", "cave_hip_cone_packed",
+    "cave_hip_packed_lds_bytes",
+)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> cave_amd/libcave_hip.so (in-tree; cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in _SOURCES)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
+           _SOURCES[0], "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class Store(C.Structure):
+    """struct cave_cone_store (include/cave_hip.h)."""
+    _fields_ = [
+        ("n", C.c_int64), ("d", C.c_int32), ("reserved", C.c_int32),
+        ("row_off", C.c_void_p), ("nnz_off", C.c_void_p), ("n_valid", C.c_void_p),
+        ("usign", C.c_void_p), ("avg", C.c_void_p), ("vkind", C.c_void_p),
+        ("rlo", C.c_void_p), ("rhi", C.c_void_p), ("ccol", C.c_void_p), ("cval", C.c_void_p),
+        ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the shared library and declare signatures.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "solver='hip' has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.cave_hip_version.restype = C.c_int32
+    lib.cave_hip_last_error.restype = C.c_char_p
+    lib.cave_hip_device_count.restype = C.c_int32
+    for name in ABI_SYMBOLS:
+        getattr(lib, name)  # AttributeError here = ABI drift between header and library
+    i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+    lib.cave_hip_default_limits.argtypes = [i64, i64, C.POINTER(i32), C.POINTER(i32)]
+    lib.cave_hip_cone_dense.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i32, i32,
+                                        vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cave_hip_pack_count.argtypes = [vp, i64, i64, i64, i32, i32, vp, vp, vp, vp]
+    lib.cave_hip_pack_fill.argtypes = [vp, i64, i64, i64, i32, i32, C.POINTER(Store), i64, vp, vp]
+    lib.cave_hip_cone_packed.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32,
+                                         vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cave_hip_packed_lds_bytes.argtypes = [i64, i32, i32]
+    for name in ("cave_hip_default_limits", "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill",
+                 "cave_hip_cone_packed", "cave_hip_packed_lds_bytes"):
+        getattr(lib, name).restype = C.c_int32
+    _lib = lib
+    return lib
+
+
+def load() -> C.CDLL:
+    """Library + a visible HIP device, or ImportError."""
+    lib = load_library()
+    import torch
+
+    if not torch.cuda.is_available() or lib.cave_hip_device_count() <= 0:
+        raise ImportError("solver='hip' needs a visible HIP device (MI355X / gfx950); none found. "
+                          "There is no CPU fallback in cave_amd.")
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().cave_hip_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def default_limits(m_max: int, d: int) -> tuple[int, int]:
+    lib = load_library()
+    cap, lds = C.c_int32(0), C.c_int32(0)
+    check(lib.cave_hip_default_limits(m_max, d, C.byref(cap), C.byref(lds)), "cave_hip_default_limits")
+    return int(cap.value), int(lds.value)
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def current_stream() -> C.c_void_p:
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

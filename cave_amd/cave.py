@@ -1,0 +1,141 @@
+"""Cone-aligned vector estimation (CaVE) losses with the MI355X `solver='hip'` backend.
+
+Host-side mirror of /root/reference src/cave.py: same class names, constructor
+arguments, call convention ``module(pred_cost, tight_ctrs) -> loss`` and error
+behaviour, for ONE backend.  The whole forward of the reference —
+sign flip, projection under no_grad, target construction, cosine loss
+(src/cave.py:55-73,121-129,197-219) — and its autograd backward are one fused
+HIP kernel launch (cave_amd/csrc/cave_hip.hip) behind a
+``torch.autograd.Function``; ``reduction`` stays in torch.
+
+The reference's CPU solvers ('clarabel', 'nnls') and its torch.compile path
+('apgd') are not re-implemented: this package has no CPU fallback, and a
+constructor asked for them says so.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .abcmodule import EPO, optModule, sense_sign
+from .dataset import PackedBatch
+from .qpsolver import cone_op_dense
+
+__all__ = ["exactConeAlignedCosine", "innerConeAlignedCosine", "abstractConeAlignedCosine", "EPO"]
+
+_REFERENCE_SOLVERS = ("apgd", "clarabel", "nnls")
+
+
+def _packed_kwargs(kwargs: dict) -> dict:
+    """Launch limits (nnz_cap, lds_bytes) only apply to the dense scan; the store knows its own."""
+    return {k: v for k, v in kwargs.items() if k in ("max_iter", "check")}
+
+
+class _ConeLossFunction(torch.autograd.Function):
+    """loss_b = 1 - cos(sign*pred_b, target_b), target constant (src/cave.py:68-72) — fused fwd+bwd."""
+
+    @staticmethod
+    def forward(ctx, pred_cost, tight_ctrs, mode, sign, inner_ratio, kwargs):
+        if isinstance(tight_ctrs, PackedBatch):  # device-resident cones, ids only (cave_amd/dataset.py)
+            o = tight_ctrs.store.cone_op(tight_ctrs.ids, pred_cost, mode, sign, inner_ratio,
+                                         outputs=("loss", "grad"), **_packed_kwargs(kwargs))
+        else:
+            o = cone_op_dense(tight_ctrs, pred_cost, mode, sign, inner_ratio, outputs=("loss", "grad"), **kwargs)
+        ctx.save_for_backward(o["grad"])
+        ctx.pred_meta = (pred_cost.device, pred_cost.dtype)
+        return o["loss"].to(device=pred_cost.device, dtype=pred_cost.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        device, dtype = ctx.pred_meta
+        g = grad * grad_out.to(device=grad.device, dtype=grad.dtype).unsqueeze(1)
+        return g.to(device=device, dtype=dtype), None, None, None, None, None
+
+
+class abstractConeAlignedCosine(optModule):
+    """CaVE family base: loss = 1 - cos(sense-flipped prediction, cone projection target)."""
+
+    def __init__(self, optmodel, processes: int = 1, reduction: str = "mean") -> None:
+        super().__init__(optmodel, processes, solve_ratio=1.0, reduction=reduction)
+
+    def _mode(self) -> int:
+        raise NotImplementedError
+
+    def forward(self, pred_cost: torch.Tensor, tight_ctrs: torch.Tensor) -> torch.Tensor:
+        sign = sense_sign(self.optmodel.modelSense)  # ValueError on a bad sense, src/cave.py:62-67
+        loss = _ConeLossFunction.apply(pred_cost, tight_ctrs, self._mode(), sign, self._inner_ratio(),
+                                       self.solver_kwargs)
+        return self._reduce(loss)
+
+    def _inner_ratio(self) -> float:
+        return 0.0
+
+    def _get_projection(self, signed_cost: torch.Tensor, tight_ctrs: torch.Tensor) -> torch.Tensor:
+        """The constant target for an already sense-flipped cost (src/cave.py:121-129,197-219)."""
+        with torch.no_grad():
+            if isinstance(tight_ctrs, PackedBatch):
+                o = tight_ctrs.store.cone_op(tight_ctrs.ids, signed_cost, self._mode(), 1.0, self._inner_ratio(),
+                                             outputs=("target",), **_packed_kwargs(self.solver_kwargs))
+            else:
+                o = cone_op_dense(tight_ctrs, signed_cost, self._mode(), 1.0, self._inner_ratio(),
+                                  outputs=("target",), **self.solver_kwargs)
+        return o["target"].to(device=signed_cost.device, dtype=signed_cost.dtype)
+
+
+class exactConeAlignedCosine(abstractConeAlignedCosine):
+    """CaVE Exact: full projection onto the cone of binding-constraint normals (src/cave.py:84-129)."""
+
+    def __init__(self, optmodel, solver: str = "hip", solver_kwargs: dict | None = None, processes: int = 1,
+                 reduction: str = "mean") -> None:
+        super().__init__(optmodel, processes, reduction)
+        if solver not in ("hip",) + _REFERENCE_SOLVERS:
+            raise ValueError(f"Invalid solver: {solver}. Must be 'hip', 'apgd', 'clarabel', or 'nnls'.")
+        if solver != "hip":
+            raise ValueError(f"solver='{solver}' is the reference's own backend and is not part of cave_amd; "
+                             "this package provides solver='hip' only (no CPU fallback).")
+        _lib.load()  # ImportError if the HIP extension or a device is missing (cf. src/cave.py:113-117)
+        self.solver = solver
+        self.solver_kwargs = dict(solver_kwargs or {})
+
+    def _mode(self) -> int:
+        return _lib.MODE_EXACT
+
+
+class innerConeAlignedCosine(exactConeAlignedCosine):
+    """CaVE+ / CaVE Hybrid (src/cave.py:132-219) with nnls-style push-inside targets.
+
+    `solver='hip'` is an exact projector like 'nnls', so the interior point comes from the convex
+    combination with the average normal (src/cave.py:216-219); ``max_iter`` is accepted for
+    signature compatibility and ignored exactly as the nnls arm ignores it (src/cave.py:302).
+    """
+
+    _INNER_DEFAULTS: dict[str, dict] = {"hip": {}}
+
+    def __init__(self, optmodel, solver: str = "hip", solver_kwargs: dict | None = None, max_iter: int = 3,
+                 solve_ratio: float = 1.0, inner_ratio: float = 0.2, processes: int = 1, reduction: str = "mean",
+                 seed: int | None = None) -> None:
+        if solver_kwargs is None:
+            solver_kwargs = dict(self._INNER_DEFAULTS.get(solver, {}))
+        super().__init__(optmodel, solver, solver_kwargs, processes, reduction)
+        if not 0 <= solve_ratio <= 1:
+            raise ValueError(f"Invalid solve_ratio {solve_ratio}. It should be between 0 and 1.")
+        if not 0 <= inner_ratio <= 1:
+            raise ValueError(f"Invalid inner_ratio {inner_ratio}. It should be between 0 and 1.")
+        self.max_iter = int(max_iter)
+        self.solve_ratio = float(solve_ratio)
+        self.inner_ratio = float(inner_ratio)
+        if seed is not None:
+            self._branch_rng = np.random.RandomState(seed)
+
+    def _mode(self) -> int:
+        # one draw per forward call decides QP vs heuristic for the whole batch (src/cave.py:201);
+        # under data parallelism every rank must construct the module with the same seed
+        if self._branch_rng.uniform() > self.solve_ratio:
+            return _lib.MODE_HEURISTIC
+        return _lib.MODE_INNER
+
+    def _inner_ratio(self) -> float:
+        return self.inner_ratio

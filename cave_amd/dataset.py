@@ -1,0 +1,167 @@
+"""Device-resident packed cone store — the replacement for per-step dense padding.
+
+The reference keeps each instance's tight-constraint normals as a ragged float32
+matrix (`optDatasetConstrs.ctrs`, /root/reference src/dataset.py:72) and its
+`collate_fn` zero-pads them to a dense (B, m_max, d) tensor every step
+(src/dataset.py:133-144): 0.18 GB per step at TSP-20/B=1024, hundreds of GB for
+TSP-100.  Cones are static per instance, so here they are packed ONCE on the GPU
+(unit rows -> a sign byte per coordinate, +a/-a equality pairs -> one free row,
+remaining rows -> CSR + CSC, plus the precomputed `_average_ctrs` vector) and a
+batch is just a tensor of instance ids.
+
+    store = ConeStore.from_ragged(dataset.ctrs)         # one-time, streams the dense form through the GPU
+    ids   = torch.tensor([...])                         # what the collate_fn replacement returns
+    out   = store.cone_op(ids, pred_cost, mode, sign)   # same fused kernel as the dense path
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .qpsolver import _raise_for_status
+
+__all__ = ["ConeStore", "PackedBatch", "collate_ids"]
+
+
+class ConeStore:
+    def __init__(self, d: int, device: torch.device):
+        self.d = int(d)
+        self.device = device
+        self.n = 0
+        self.t: dict[str, torch.Tensor] = {}
+        self.max_rows = 0
+        self.max_nnz = 0
+        self._c = None
+
+    # ------------------------------------------------------------------ build
+    @classmethod
+    def from_dense(cls, tight_ctrs: torch.Tensor, chunk: int = 4096) -> "ConeStore":
+        """Pack a zero-padded (N, m_max, d) tensor (host or device); streamed in chunks of instances."""
+        return cls.from_chunks([tight_ctrs[i:i + chunk] for i in range(0, tight_ctrs.shape[0], chunk)])
+
+    @classmethod
+    def from_ragged(cls, ctrs: list[torch.Tensor], chunk: int = 1024) -> "ConeStore":
+        """Pack `optDatasetConstrs.ctrs` (list of (m_i, d) tensors), padding one chunk at a time."""
+        from torch.nn.utils.rnn import pad_sequence
+
+        chunks = [pad_sequence(ctrs[i:i + chunk], batch_first=True, padding_value=0.0)
+                  for i in range(0, len(ctrs), chunk)]
+        return cls.from_chunks(chunks)
+
+    @classmethod
+    def from_chunks(cls, chunks: list[torch.Tensor]) -> "ConeStore":
+        lib = _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d = int(chunks[0].shape[2])
+        self = cls(d, dev)
+        stream = _lib.current_stream()
+        # pass 1: counts
+        counts = []
+        for ch in chunks:
+            x = ch.to(device=dev, dtype=torch.float32).contiguous()
+            B, m, _ = x.shape
+            n_rows = torch.empty(B, dtype=torch.int32, device=dev)
+            n_nnz = torch.empty(B, dtype=torch.int32, device=dev)
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+            _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, 0, 0, _lib.ptr(n_rows), _lib.ptr(n_nnz),
+                                               _lib.ptr(status), stream), "cave_hip_pack_count")
+            _raise_for_status(status, "ConeStore pack")
+            counts.append((n_rows, n_nnz))
+        n_rows = torch.cat([c[0] for c in counts]).to(torch.int64)
+        n_nnz = torch.cat([c[1] for c in counts]).to(torch.int64)
+        N = int(n_rows.numel())
+        z = torch.zeros(1, dtype=torch.int64, device=dev)
+        row_off = torch.cat([z, torch.cumsum(n_rows, 0)])
+        nnz_off = torch.cat([z, torch.cumsum(n_nnz, 0)])
+        R, Z = int(row_off[-1]), int(nnz_off[-1])
+        self.n = N
+        self.max_rows = int(n_rows.max()) if N else 0
+        self.max_nnz = int(n_nnz.max()) if N else 0
+        t = self.t
+        t["row_off"], t["nnz_off"] = row_off, nnz_off
+        t["n_valid"] = torch.zeros(N, dtype=torch.int32, device=dev)
+        t["usign"] = torch.zeros(N * d, dtype=torch.uint8, device=dev)
+        t["avg"] = torch.zeros(N * d, dtype=torch.float32, device=dev)
+        t["vkind"] = torch.zeros(max(R, 1), dtype=torch.uint8, device=dev)
+        t["rlo"] = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+        t["rhi"] = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+        t["ccol"] = torch.zeros(max(Z, 1), dtype=torch.int16, device=dev)
+        t["cval"] = torch.zeros(max(Z, 1), dtype=torch.float32, device=dev)
+        t["cptr"] = torch.zeros(N * (d + 1), dtype=torch.int32, device=dev)
+        t["cvar"] = torch.zeros(max(Z, 1), dtype=torch.int16, device=dev)
+        t["cvalc"] = torch.zeros(max(Z, 1), dtype=torch.float32, device=dev)
+        self._c = _lib.Store(n=N, d=d, reserved=0, **{k: v.data_ptr() for k, v in t.items()})
+        # pass 2: fill
+        slot = 0
+        for ch in chunks:
+            x = ch.to(device=dev, dtype=torch.float32).contiguous()
+            B, m, _ = x.shape
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+            _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, 0, 0, C.byref(self._c), slot, _lib.ptr(status),
+                                              stream), "cave_hip_pack_fill")
+            _raise_for_status(status, "ConeStore fill")
+            slot += B
+        self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz))
+        if self.lds_bytes <= 0:
+            raise RuntimeError("ConeStore: largest instance does not fit a 160 KiB LDS arena")
+        return self
+
+    # -------------------------------------------------------------------- use
+    def nbytes(self) -> int:
+        return sum(v.numel() * v.element_size() for v in self.t.values())
+
+    def algorithmic_bytes(self, ids: torch.Tensor) -> int:
+        """Bytes one projection pass must touch for these instances: packed rows + y in, proj/rnorm out
+        (packed format as actually stored: 6 B per CSR entry + 6 B per CSC entry)."""
+        nz = (self.t["nnz_off"][ids + 1] - self.t["nnz_off"][ids]).sum().item()
+        rows = (self.t["row_off"][ids + 1] - self.t["row_off"][ids]).sum().item()
+        B = ids.numel()
+        return int(12 * nz + 9 * rows + B * (self.d * (1 + 4) + 4 * (self.d + 1) + 8 * self.d + 4))
+
+    def cone_op(self, ids: torch.Tensor, pred_cost: torch.Tensor | None, mode: int, sign: float = 1.0,
+                inner_ratio: float = 0.2, *, max_iter: int = 0, check: bool = True,
+                outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
+        lib = _lib.load()
+        dev = self.device
+        ids = ids.to(device=dev, dtype=torch.int64).contiguous()
+        B, d = int(ids.numel()), self.d
+        pred = None if pred_cost is None else pred_cost.detach().to(device=dev, dtype=torch.float32).contiguous()
+        out: dict[str, torch.Tensor] = {}
+        with torch.cuda.device(dev):
+            for name in outputs:
+                shape = (B,) if name in ("rnorm", "loss") else (B, d)
+                out[name] = torch.empty(shape, dtype=torch.float32, device=dev)
+            status = torch.empty(B, dtype=torch.int32, device=dev)
+            iters = torch.empty(B, dtype=torch.int32, device=dev)
+            out["status"], out["iters"] = status, iters
+            if B == 0:
+                return out
+            rc = lib.cave_hip_cone_packed(
+                C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
+                int(max_iter), self.lds_bytes,
+                _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
+                _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+                _lib.current_stream())
+            _lib.check(rc, "cave_hip_cone_packed")
+            if check:
+                _raise_for_status(status, "solver='hip' (packed)")
+        return out
+
+
+class PackedBatch:
+    """What a loss module receives instead of the dense (B, m_max, d) tensor: store + instance ids."""
+
+    def __init__(self, store: ConeStore, ids: torch.Tensor):
+        self.store = store
+        self.ids = ids
+
+
+def collate_ids(batch):
+    """Drop-in for the reference `collate_fn` (src/dataset.py:133-144) when the dataset yields
+    (x, c, w, z, instance_id): stacks the dense fields and returns the ids instead of padded cones."""
+    x, c, w, z, ids = zip(*batch)
+    return (torch.stack(x, 0), torch.stack(c, 0), torch.stack(w, 0), torch.stack(z, 0),
+            torch.as_tensor(ids, dtype=torch.int64))

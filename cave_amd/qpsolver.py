@@ -1,0 +1,130 @@
+"""Batched cone projection on MI355X — the `solver='hip'` arm.
+
+Host-side mirror of the reference's plug point: a lazily imported function
+``f(tight_ctrs, signed_cost, **solver_kwargs) -> (proj (B,d), rnorm (B,))``
+living next to ``project_apgd`` (/root/reference src/qpsolver.py:11-63, called
+from ``_batch_project`` src/cave.py:242-244), but with **nnls semantics**
+(src/cave.py:298-309): exact Euclidean projection onto
+``cone{lam @ ctrs_b : lam >= 0}``, zero-padded rows ignored, empty cone returns
+the input, ``rnorm`` is the un-squared residual norm.
+
+Everything runs in one HIP kernel launch per call (cave_amd/csrc/cave_hip.hip);
+this module only marshals pointers, picks launch limits and turns per-instance
+status codes into the reference's error behaviour.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (MODE_AVG, MODE_EXACT, MODE_HEURISTIC, MODE_INNER, MODE_PROJECT, ST_BAD_INPUT,
+                   ST_NOT_CONVERGED, ST_OK, ST_TOO_LARGE)
+
+__all__ = ["project_hip", "average_ctrs_hip", "cone_op_dense", "HipSolverError"]
+
+
+class HipSolverError(RuntimeError):
+    """Per-instance solver failure (SciPy's nnls raises RuntimeError on its iteration cap, src/cave.py:307)."""
+
+
+def _as_device(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _grow_limits(m: int, d: int) -> tuple[int, int]:
+    """Largest arena a workgroup can have (160 KiB) and the nnz capacity that fits in it."""
+    other = 4 * (m + 1) + 4 * d + d + m + 4 * (d + 1) + 12 * d + 16 * d + 512
+    reserve = 8 * 64 * 65 + 6 * 8 * 64 + 40 * min(m, 512)  # H for p = 64 + p-vectors + row lists
+    cap = max(64, (_lib.MAX_LDS - other - reserve) // 12)  # 6 B CSR + 6 B CSC per entry
+    return int(min(cap, max(m * d, 64))), _lib.MAX_LDS
+
+
+def _raise_for_status(status: torch.Tensor, what: str) -> None:
+    st = status.cpu()
+    if bool((st == ST_OK).all()):
+        return
+    bad = int((st != ST_OK).sum())
+    first = int((st != ST_OK).nonzero()[0])
+    code = int(st[first])
+    if code == ST_NOT_CONVERGED:
+        raise HipSolverError(f"{what}: Maximum number of iterations reached ({bad} instance(s), first index {first}).")
+    if code == ST_TOO_LARGE:
+        raise HipSolverError(
+            f"{what}: {bad} cone(s) (first index {first}) do not fit one workgroup's 160 KiB LDS arena "
+            "(more than 64 reduced rows, or too many non-zeros); larger cones are not supported by this build.")
+    if code == ST_BAD_INPUT:
+        raise ValueError(f"{what}: non-finite input in {bad} instance(s), first index {first}.")
+    raise HipSolverError(f"{what}: unknown status {code}")
+
+
+def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode: int, sign: float = 1.0,
+                  inner_ratio: float = 0.2, *, max_iter: int = 0, nnz_cap: int = 0, lds_bytes: int = 0,
+                  check: bool = True, outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
+    """Run the fused per-instance kernel on the reference's dense wire format.
+
+    tight_ctrs (B, m_max, d) float32 zero-padded (src/dataset.py:143); pred_cost (B, d).
+    ``outputs`` selects which of proj / rnorm / target / loss / grad are materialised.
+    With ``check=True`` (default) the per-instance status is read back (one host sync):
+    an LDS overflow is retried once with the largest arena, anything else raises.
+    """
+    lib = _lib.load()
+    if tight_ctrs.dim() != 3:
+        raise ValueError("tight_ctrs must have shape (B, m_max, d)")
+    B, m, d = tight_ctrs.shape
+    dev = tight_ctrs.device if tight_ctrs.is_cuda else (
+        pred_cost.device if pred_cost is not None and pred_cost.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    ctrs = _as_device(tight_ctrs, dev)
+    pred = None
+    if pred_cost is not None:
+        if pred_cost.shape != (B, d):
+            raise ValueError(f"pred_cost must have shape ({B}, {d}), got {tuple(pred_cost.shape)}")
+        pred = _as_device(pred_cost, dev)
+    elif mode != MODE_AVG:
+        raise ValueError("pred_cost is required")
+    out: dict[str, torch.Tensor] = {}
+    with torch.cuda.device(dev):
+        for name in outputs:
+            shape = (B,) if name in ("rnorm", "loss") else (B, d)
+            out[name] = torch.empty(shape, dtype=torch.float32, device=dev)
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        out["status"], out["iters"] = status, iters
+        if B == 0:
+            return out
+
+        def launch(cap: int, lds: int) -> None:
+            rc = lib.cave_hip_cone_dense(
+                _lib.ptr(ctrs), _lib.ptr(pred), B, m, d, int(mode), float(sign), float(inner_ratio),
+                int(max_iter), int(cap), int(lds),
+                _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
+                _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+                _lib.current_stream())
+            _lib.check(rc, "cave_hip_cone_dense")
+
+        launch(nnz_cap, lds_bytes)
+        if check:
+            if bool((status == ST_TOO_LARGE).any()) and lds_bytes == 0:
+                cap, lds = _grow_limits(m, d)
+                launch(max(cap, nnz_cap), lds)
+            _raise_for_status(status, "solver='hip'")
+    return out
+
+
+def project_hip(tight_ctrs: torch.Tensor, signed_cost: torch.Tensor, max_iter: int = 0, nnz_cap: int = 0,
+                lds_bytes: int = 0, check: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+    """(proj, rnorm) on signed_cost's device and dtype — `_batch_project(..., 'nnls')` (src/cave.py:231-264).
+
+    ``max_iter`` caps the Newton iterations of the GPU solver (0 = default 100); unlike
+    Clarabel's ``max_iter`` it does not produce an interior iterate (src/cave.py:302).
+    """
+    o = cone_op_dense(tight_ctrs, signed_cost, MODE_PROJECT, 1.0, 0.0, max_iter=max_iter, nnz_cap=nnz_cap,
+                      lds_bytes=lds_bytes, check=check, outputs=("proj", "rnorm"))
+    device, dtype = signed_cost.device, signed_cost.dtype
+    return o["proj"].to(device=device, dtype=dtype), o["rnorm"].to(device=device, dtype=dtype)
+
+
+def average_ctrs_hip(tight_ctrs: torch.Tensor) -> torch.Tensor:
+    """`_average_ctrs` (src/cave.py:222-228) in one streaming pass."""
+    o = cone_op_dense(tight_ctrs, None, MODE_AVG, outputs=("target",))
+    return o["target"].to(device=tight_ctrs.device, dtype=tight_ctrs.dtype)

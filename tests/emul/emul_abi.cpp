@@ -22,7 +22,9 @@ int32_t cave_emul_cone_dense(const float* ctrs, const float* pred, int64_t B, in
                              float sign, float inner_ratio, int32_t max_iter, int32_t nnz_cap, int32_t lds_bytes,
                              float* proj, float* rnorm, float* target, float* loss, float* grad, int32_t* status,
                              int32_t* iters) {
-  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return CAVE_E_INVALID;
+  // explicit limits are taken as given, even beyond the 160 KiB a real workgroup has: this lets
+  // the CPU tier validate the algorithm at sizes (TSP-50) the round-1 kernels cannot hold in LDS yet
+  if (!(nnz_cap > 0 && lds_bytes > 0) && !resolve_limits(m_max, d, nnz_cap, lds_bytes)) return CAVE_E_INVALID;
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
   P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;

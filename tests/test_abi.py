@@ -1,0 +1,97 @@
+"""CPU tier: the C-ABI library builds for gfx950, loads, exports every symbol the header declares,
+and the Python host layer enforces the reference's error behaviour.  No compute calls (no GPU here)."""
+
+import os
+import re
+from unittest.mock import Mock
+
+import pytest
+
+from cave_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    _lib.build()
+    lib = _lib.load_library()
+    hdr = open(os.path.join(ROOT, "include", "cave_hip.h")).read()
+    declared = set(re.findall(r"\b(cave_hip_\w+)\s*\(", hdr))
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cave_hip_version() == 1
+    assert lib.cave_hip_device_count() >= 0
+    assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
+
+
+def test_default_limits_and_arg_validation():
+    cap, lds = _lib.default_limits(235, 190)  # TSP-20
+    assert 1500 <= cap <= 235 * 190 and 0 < lds <= 40 * 1024  # >= 4 workgroups per CU
+    cap, lds = _lib.default_limits(15, 10)
+    assert cap == 150 and lds <= 16 * 1024
+    lib = _lib.load_library()
+    # bad shapes are rejected before any launch (works without a GPU)
+    assert lib.cave_hip_cone_dense(None, None, 1, 4, 0, 0, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    assert b"bad shape" in lib.cave_hip_last_error()
+    assert lib.cave_hip_cone_dense(None, None, 1, 4, 70000, 0, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.cave_hip_cone_dense(None, None, 1, 4, 4, 9, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.cave_hip_cone_dense(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == 0  # B == 0
+    assert lib.cave_hip_packed_lds_bytes(190, 26, 700) > 0
+    assert lib.cave_hip_packed_lds_bytes(190, 5000, 700) == -1
+
+
+def test_status_codes_match_header():
+    hdr = open(os.path.join(ROOT, "include", "cave_hip.h")).read()
+    for name, val in (("CAVE_ST_OK", _lib.ST_OK), ("CAVE_ST_NOT_CONVERGED", _lib.ST_NOT_CONVERGED),
+                      ("CAVE_ST_TOO_LARGE", _lib.ST_TOO_LARGE), ("CAVE_ST_BAD_INPUT", _lib.ST_BAD_INPUT),
+                      ("CAVE_MODE_PROJECT", _lib.MODE_PROJECT), ("CAVE_MODE_EXACT", _lib.MODE_EXACT),
+                      ("CAVE_MODE_INNER", _lib.MODE_INNER), ("CAVE_MODE_HEURISTIC", _lib.MODE_HEURISTIC),
+                      ("CAVE_MODE_AVG", _lib.MODE_AVG)):
+        assert int(re.search(rf"#define {name} (\d+)", hdr).group(1)) == val
+
+
+def _model(sense):
+    m = Mock()
+    m.modelSense = sense
+    return m
+
+
+def test_constructor_error_behaviour(monkeypatch):
+    """test/test_func.py:195-214 restated for solver='hip'."""
+    import torch
+
+    from cave_amd.cave import EPO, exactConeAlignedCosine, innerConeAlignedCosine
+
+    with pytest.raises(ValueError):
+        exactConeAlignedCosine(_model(EPO.MINIMIZE), solver="bogus")
+    with pytest.raises(ValueError):  # the reference's CPU backends are not shipped here
+        exactConeAlignedCosine(_model(EPO.MINIMIZE), solver="nnls")
+    if not torch.cuda.is_available():
+        with pytest.raises(ImportError):  # no device -> loud failure, no fallback (cf. src/cave.py:113-117)
+            exactConeAlignedCosine(_model(EPO.MINIMIZE), solver="hip")
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    with pytest.raises(ValueError):
+        innerConeAlignedCosine(_model(EPO.MINIMIZE), solve_ratio=1.5)
+    with pytest.raises(ValueError):
+        innerConeAlignedCosine(_model(EPO.MINIMIZE), inner_ratio=-0.1)
+    m = innerConeAlignedCosine(_model(EPO.MINIMIZE), solver_kwargs={"max_iter": 50}, seed=42)
+    assert m.solver_kwargs == {"max_iter": 50} and m.max_iter == 3 and m.solver == "hip"
+    # seeded branch RNG: same stream as the reference (src/cave.py:195,201)
+    assert abs(m._branch_rng.uniform() - 0.3745401188473625) < 1e-15
+    # sense handling (src/cave.py:62-67)
+    from cave_amd.abcmodule import sense_sign
+
+    assert sense_sign(EPO.MINIMIZE) == -1.0 and sense_sign(EPO.MAXIMIZE) == 1.0
+    with pytest.raises(ValueError):
+        sense_sign("sideways")
+
+
+def test_no_oracle_or_emul_in_product_path():
+    """The package must never import the oracle or the serial test build."""
+    pkg = os.path.join(ROOT, "cave_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no oracle", "") or fn == "__init__.py" and False, fn
+            assert "emul" not in src, fn
