@@ -20,12 +20,22 @@
 
 namespace cave {
 
+#ifdef CAVE_STAMPS
+__device__ unsigned long long g_stamp_buf[16 * 8192];
+#endif
+
 __global__ __launch_bounds__(64) void cone_dense_kernel(DenseParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WaveCtx c;
   c.lane = (int)threadIdx.x;
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
+#ifdef CAVE_STAMPS
+    for (int i = 0; i < 16; ++i) c.st[i] = 0;
+#endif
     run_dense_instance(c, smem, P, b);
+#ifdef CAVE_STAMPS
+    if (c.lane == 0 && b < 8192) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
+#endif
     __syncthreads();
   }
 }
@@ -74,6 +84,15 @@ using namespace cave;
 extern "C" {
 
 int32_t cave_hip_version(void) { return CAVE_HIP_ABI_VERSION; }
+
+#ifdef CAVE_STAMPS
+// diagnostic build only: read and clear the per-phase cycle accumulators
+int32_t cave_hip_debug_stamps(unsigned long long* out, int n_inst) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(cave::g_stamp_buf), sizeof(unsigned long long) * 16 * (size_t)n_inst);
+  return 0;
+}
+#endif
 
 const char* cave_hip_last_error(void) { return g_err; }
 

@@ -17,6 +17,17 @@
 #define CAVE_HD inline
 #endif
 
+// ---- optional phase timing (diagnostic builds only: -DCAVE_STAMPS; never in the shipped library).
+// Cycle deltas are summed in per-wave registers (WaveCtx::st) and stored once per instance.
+#if defined(CAVE_STAMPS) && defined(__HIPCC__)
+#define CAVE_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
+#define CAVE_ACC(slot) do { unsigned long long _t1 = __builtin_amdgcn_s_memtime(); \
+    c.st[slot] += _t1 - _t0; _t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CAVE_T0() do {} while (0)
+#define CAVE_ACC(slot) do {} while (0)
+#endif
+
 namespace cave {
 
 // per-instance status codes (also in include/cave_hip.h)
@@ -45,21 +56,32 @@ static constexpr float kInsideRnorm = 1e-7f;    // src/cave.py:218
 // row tags produced by classification
 enum : uint8_t { ROW_DROP = 0, ROW_UNIT = 1, ROW_GENERAL = 2, ROW_AVG_VALID = 0x10 };
 
-// Bump allocator over one LDS (or heap) buffer.  All lanes run it uniformly.
+// Two-ended bump allocator over one LDS (or heap) buffer; all lanes run it uniformly.
+// Persistent arrays grow from the bottom, build-phase temporaries from the top, so the
+// temporaries can be dropped (release_top) before the solver's work arrays are carved.
 struct Arena {
   unsigned char* base;
-  uint32_t off;
+  uint32_t off;   // bottom watermark
+  uint32_t top;   // top watermark (bytes [top, cap) are in use by temporaries)
   uint32_t cap;
   bool ovf;
-  CAVE_HD void init(unsigned char* b, uint32_t c) { base = b; off = 0; cap = c; ovf = false; }
+  CAVE_HD void init(unsigned char* b, uint32_t c) { base = b; off = 0; cap = c & ~7u; top = cap; ovf = false; }
   template <class T>
   CAVE_HD T* get(uint32_t n) {
     uint32_t a = (off + 7u) & ~7u;
     uint64_t e = (uint64_t)a + (uint64_t)n * sizeof(T);
-    if (e > cap) { ovf = true; return reinterpret_cast<T*>(base); }
+    if (e > top) { ovf = true; return reinterpret_cast<T*>(base); }
     off = (uint32_t)e;
     return reinterpret_cast<T*>(base + a);
   }
+  template <class T>
+  CAVE_HD T* get_top(uint32_t n) {
+    uint64_t bytes = ((uint64_t)n * sizeof(T) + 7u) & ~7ull;
+    if (bytes > top || top - bytes < off) { ovf = true; return reinterpret_cast<T*>(base); }
+    top -= (uint32_t)bytes;
+    return reinterpret_cast<T*>(base + top);
+  }
+  CAVE_HD void release_top() { top = cap; }
 };
 
 // What the Newton solver needs to know about one cone (all pointers LDS-resident).
@@ -76,12 +98,15 @@ struct SolveView {
   const uint16_t* cvar;
   const float* cvalc;
   const uint8_t* usign;   // [d]  bit0: +e_k row present, bit1: -e_k row present
+  int nlong;              // reduced rows with more than kLongRow entries ...
+  const uint32_t* longrow;  // ... and their indices
 };
 
 struct SolveWork {
   float* y;        // [d]
   double* res;     // [d]  residual y - M^T theta (unclipped while iterating, clipped on return)
   double* q;       // [d]  M^T (search direction)
+  double* rc;      // [d]  Pi(res)
   double* theta;   // [p]
   double* ttry;    // [p]
   double* g;       // [p]

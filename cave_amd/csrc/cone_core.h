@@ -54,11 +54,12 @@ template <class C>
 CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   const int d = cb.d, m = cb.m;
   const int NT = C::NT;
+  CAVE_T0();
   // 1. row counts -> row pointers
   c.exclusive_scan_u32(cb.rptr, m + 1);
-  cb.ucnt = ar.get<uint32_t>(d);
+  cb.ucnt = ar.get_top<uint32_t>(d);
   cb.usign = ar.get<uint8_t>(d);
-  cb.rowtag = ar.get<uint8_t>(m > 0 ? m : 1);
+  cb.rowtag = ar.get_top<uint8_t>(m > 0 ? m : 1);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int k = c.tid(); k < d; k += NT) cb.ucnt[k] = 0;
   c.sync();
@@ -93,24 +94,22 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   c.sync();
   for (int k = c.tid(); k < d; k += NT)
     cb.usign[k] = (uint8_t)(((cb.ucnt[k] & 0xffffu) ? 1 : 0) | ((cb.ucnt[k] >> 16) ? 2 : 0));
+  CAVE_ACC(11);
   // 3. ordered list of general rows
   const int pr = cb.p_raw;
-  cb.vraw = ar.get<uint32_t>(pr > 0 ? pr : 1);
-  cb.vnorm = ar.get<float>(pr > 0 ? pr : 1);
-  uint32_t* twin = ar.get<uint32_t>(pr > 0 ? pr : 1);
-  uint8_t* keep = ar.get<uint8_t>(pr > 0 ? pr : 1);
-  cb.mlo = ar.get<uint32_t>(pr > 0 ? pr : 1);
-  cb.mhi = ar.get<uint32_t>(pr > 0 ? pr : 1);
-  cb.vkind = ar.get<uint8_t>(pr > 0 ? pr : 1);
+  cb.vraw = ar.get_top<uint32_t>(pr > 0 ? pr : 1);
+  cb.vnorm = ar.get_top<float>(pr > 0 ? pr : 1);
+  uint32_t* twin = ar.get_top<uint32_t>(pr > 0 ? pr : 1);
+  uint8_t* keep = ar.get_top<uint8_t>(pr > 0 ? pr : 1);
   cb.cptr = ar.get<uint32_t>(d + 1);
   if (ar.ovf) return ST_TOO_LARGE;
   c.compact_mask_u8(cb.rowtag, m, 0x0F, ROW_GENERAL, cb.vraw);
   c.sync();
   // 4. pair detection by (hash(+a), hash(-a)); hashes live in scratch carved after
   //    the persistent arrays and released again below.
-  const uint32_t arena_mark = ar.off;
-  uint64_t* hp = ar.get<uint64_t>(pr > 0 ? pr : 1);
-  uint64_t* hn = ar.get<uint64_t>(pr > 0 ? pr : 1);
+  const uint32_t top_mark = ar.top;
+  uint64_t* hp = ar.get_top<uint64_t>(pr > 0 ? pr : 1);
+  uint64_t* hn = ar.get_top<uint64_t>(pr > 0 ? pr : 1);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int i = c.tid(); i < pr; i += NT) {
     uint32_t r = cb.vraw[i];
@@ -159,12 +158,17 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
     keep[i] = (uint8_t)((paired && t < (uint32_t)i) ? 0 : (paired ? 2 : 1));
   }
   c.sync();
-  ar.off = arena_mark;  // release hash scratch
+  ar.top = top_mark;  // release hash scratch
+  CAVE_ACC(12);
   // 5. reduced variable list (ordered): reuse twin[] as the compacted index list
   uint32_t* vidx = twin;  // overwritten below only after keep[] has been fully derived
   cb.p = (int)c.compact_nonzero_u8(keep, pr, vidx);
   c.sync();
   const int p = cb.p;
+  cb.mlo = ar.get<uint32_t>(p > 0 ? p : 1);
+  cb.mhi = ar.get<uint32_t>(p > 0 ? p : 1);
+  cb.vkind = ar.get<uint8_t>(p > 0 ? p : 1);
+  if (ar.ovf) return ST_TOO_LARGE;
   uint32_t nnzM_local = 0;
   for (int i = c.tid(); i < p; i += NT) {
     uint32_t src = vidx[i];
@@ -179,8 +183,8 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   // 6. CSC of the reduced rows
   cb.cvar = ar.get<uint16_t>(cb.nnzM > 0 ? cb.nnzM : 1);
   cb.cvalc = ar.get<float>(cb.nnzM > 0 ? cb.nnzM : 1);
-  const uint32_t mark2 = ar.off;
-  uint32_t* fill = ar.get<uint32_t>(d);
+  const uint32_t top_mark2 = ar.top;
+  uint32_t* fill = ar.get_top<uint32_t>(d);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int k = c.tid(); k <= d; k += NT) cb.cptr[k] = 0;
   for (int k = c.tid(); k < d; k += NT) fill[k] = 0;
@@ -201,7 +205,8 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
     }
     c.sync();
   }
-  ar.off = mark2;  // release fill[]
+  ar.top = top_mark2;  // release fill[]
+  CAVE_ACC(13);
   return ST_OK;
 }
 
@@ -244,15 +249,50 @@ CAVE_HD void gather_mt(C& c, const SolveView& v, const float* base, const double
   c.sync();
 }
 
-// 1/2 || Pi(r) ||^2
+// rc = Pi(r);  returns 1/2 || rc ||^2
 template <class C>
-CAVE_HD double half_sq_clipped(C& c, const SolveView& v, const double* r) {
+CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double* rc) {
   double acc = 0.0;
   for (int k = c.tid(); k < v.d; k += C::NT) {
     double t = clip_unit(r[k], v.usign[k]);
+    rc[k] = t;
     acc += t * t;
   }
-  return 0.5 * c.reduce_sum(acc);
+  double f = 0.5 * c.reduce_sum(acc);
+  c.sync();
+  return f;
+}
+
+// g = -M rc.  Rows are shared by TEAM adjacent lanes (fixed reduction tree); rows longer than
+// kLongRow entries are summed by the whole team of NT lanes, one row at a time.
+static constexpr uint32_t kLongRow = 64;
+
+template <class C>
+CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
+  constexpr int TEAM = C::TEAM;
+  constexpr int RPP = C::NT / TEAM;  // rows per pass
+  const int sub = c.tid() % TEAM;
+  for (int base = 0; base < v.p; base += RPP) {
+    const int i = base + c.tid() / TEAM;
+    const bool valid = i < v.p;
+    double part = 0.0;
+    uint32_t lo = 0, hi = 0;
+    if (valid) { lo = v.mlo[i]; hi = v.mhi[i]; }
+    const bool is_long = (hi - lo) > kLongRow;
+    if (valid && !is_long)
+      for (uint32_t e = lo + sub; e < hi; e += TEAM) part -= (double)v.eval[e] * rc[v.ecol[e]];
+    part = c.team_reduce_sum(part);
+    if (valid && !is_long && sub == 0) g[i] = part;
+  }
+  for (int li = 0; li < v.nlong; ++li) {
+    const int i = (int)v.longrow[li];
+    const uint32_t lo = v.mlo[i], hi = v.mhi[i];
+    double part = 0.0;
+    for (uint32_t e = lo + c.tid(); e < hi; e += C::NT) part -= (double)v.eval[e] * rc[v.ecol[e]];
+    part = c.reduce_sum(part);
+    if (c.tid() == 0) g[i] = part;
+  }
+  c.sync();
 }
 
 // phi'(alpha) and phi''(alpha) of phi(alpha) = 1/2 || Pi(r - alpha q) ||^2
@@ -289,27 +329,25 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
   double* theta = w.theta;
   double* tc = w.ttry;  // working point of the inner loop
   double* r = w.res;    // UNCLIPPED residual y - M^T theta during the iteration
+  double* rc = w.rc;    // its clipped image Pi(r)
   for (int i = c.tid(); i < p; i += NT) theta[i] = 0.0;
   double yy = 0.0;
   for (int k = c.tid(); k < d; k += NT) { yy += (double)w.y[k] * (double)w.y[k]; r[k] = (double)w.y[k]; }
   yy = c.reduce_sum(yy);
   c.sync();
-  double f = half_sq_clipped(c, v, r);
+  double f = refresh_clipped(c, v, r, rc);
   const int ldh = w.ldh;
   double g0n = 0.0;
   double reg_rel = 1e-10;  // Levenberg shift relative to max diag(H); raised when a step stalls
   bool converged = (p == 0);
   int it = 0;
+  CAVE_T0();
   for (; p > 0 && it < max_iter; ++it) {
     // gradient g = -M Pi(r) and projected-gradient norm
+    gradient(c, v, rc, w.g);
     double pgmax = 0.0;
     for (int i = c.tid(); i < p; i += NT) {
-      double gi = 0.0;
-      for (uint32_t e = v.mlo[i]; e < v.mhi[i]; ++e) {
-        uint16_t col = v.ecol[e];
-        gi -= (double)v.eval[e] * clip_unit(r[col], v.usign[col]);
-      }
-      w.g[i] = gi;
+      double gi = w.g[i];
       double pg = (v.vkind[i] || theta[i] > 0.0) ? gi : fmin(gi, 0.0);
       pgmax = fmax(pgmax, fabs(pg));
     }
@@ -318,12 +356,13 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
 #ifdef CAVE_TRACE
     printf("it %d f %.10e pgn %.6e\n", it, f, pgn);
 #endif
+    CAVE_ACC(2);
     if (!(pgn > tol * g0n) || f <= 1e-30 * yy) { converged = true; break; }
     // generalised Hessian H = M D M^T, D = [Pi(r) != 0], by column outer products
     for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
     c.sync();
     for (int k = c.tid(); k < d; k += NT) {
-      if (clip_unit(r[k], v.usign[k]) == 0.0) continue;
+      if (rc[k] == 0.0) continue;
       uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
       for (uint32_t e1 = lo; e1 < hi; ++e1) {
         uint32_t a = v.cvar[e1];
@@ -338,6 +377,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
       }
     }
     c.sync();
+    CAVE_ACC(3);
     // ---- model minimisation over theta >= 0 (attempt 0: free every bound variable with
     //      a negative multiplier; attempt 1, only if that made no move: free the most negative one)
     bool moved = false;
@@ -363,8 +403,10 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
         double* rhs = w.g2;
         for (int i = c.tid(); i < p; i += NT) rhs[i] = w.act[i] ? -tc[i] : -w.dv[i];
         c.sync();
+        CAVE_ACC(4);
         c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
         c.sync();
+        CAVE_ACC(5);
         // ratio test to the first blocking bound
         double amin = 2.0;
         for (int i = c.tid(); i < p; i += NT) {
@@ -376,13 +418,15 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
         amin = -c.reduce_max(-amin);
         const bool blocked = amin < 1.0;
         const double a = blocked ? fmax(amin, 0.0) : 1.0;
-        // model gradient update  gm += a * H step   (before tc/act change)
-        for (int i = c.tid(); i < p; i += NT) {
-          double s = 0.0;
-          for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
-          rhs[i] = s;  // rhs is dead until the next inner round
+        // model gradient update  gm += a * H step  (only needed if another inner round follows)
+        if (blocked) {
+          for (int i = c.tid(); i < p; i += NT) {
+            double s = 0.0;
+            for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
+            rhs[i] = s;  // rhs is dead until the next inner round
+          }
+          c.sync();
         }
-        c.sync();
         for (int i = c.tid(); i < p; i += NT) {
           double t = tc[i] + w.step[i];
           double tn = tc[i] + a * w.step[i];
@@ -392,7 +436,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
           }
           if (w.act[i]) tn = 0.0;
           tc[i] = tn;
-          w.dv[i] += a * rhs[i];
+          if (blocked) w.dv[i] += a * rhs[i];
         }
         c.sync();
         if (!blocked) break;
@@ -401,6 +445,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
       for (int i = c.tid(); i < p; i += NT) mv = fmax(mv, fabs(tc[i] - theta[i]));
       moved = c.reduce_max(mv) > 0.0;
     }
+    CAVE_ACC(4);
     if (!moved) { converged = !(pgn > 1e-6 * g0n); break; }
     // ---- exact line search on the true f along dv = tc - theta
     double psi0 = 0.0, amax = 1e300;
@@ -416,6 +461,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
     c.sync();
     if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n); break; }
     gather_mt(c, v, nullptr, w.dv, 1.0, w.q);  // q = M^T dv, so r(alpha) = r - alpha q
+    CAVE_ACC(6);
     double alpha = 1.0, lo = 0.0, hi = amax;
     double d1, d2;
     const double psitol = 1e-12 * fabs(psi0);
@@ -445,8 +491,10 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
       theta[i] = t;
     }
     c.sync();
+    CAVE_ACC(7);
     gather_mt(c, v, w.y, theta, -1.0, r);  // fresh residual (no drift)
-    double fn = half_sq_clipped(c, v, r);
+    double fn = refresh_clipped(c, v, r, rc);
+    CAVE_ACC(8);
     // An exact line search along the Newton direction that no longer lowers f beyond
     // round-off means the Newton decrement is ~0: by the projection inequality
     // ||proj - proj*||^2 <= 2 (f - f*), so this is fp32-exact long before it triggers.
@@ -462,7 +510,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
     } else if (reg_rel > 1e-10) reg_rel *= 0.1;
   }
   // leave the clipped residual behind for the epilogue
-  for (int k = c.tid(); k < d; k += NT) r[k] = clip_unit(r[k], v.usign[k]);
+  for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];
   c.sync();
   if (!converged) out.status = ST_NOT_CONVERGED;
   if (!(f == f) || !(yy == yy)) out.status = ST_BAD_INPUT;

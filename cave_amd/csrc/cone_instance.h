@@ -82,12 +82,14 @@ CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, i
   cb.m = m;
   cb.ecol = ar.get<uint16_t>(cap);
   cb.eval = ar.get<float>(cap);
-  cb.rptr = ar.get<uint32_t>((uint32_t)m + 1u);
+  cb.rptr = ar.get_top<uint32_t>((uint32_t)m + 1u);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
   c.sync();
+  CAVE_T0();
   uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, (uint32_t)d, cb.ecol, cb.eval, cb.rptr, cap);
   c.sync();
+  CAVE_ACC(10);
   if (nnz > cap) return ST_TOO_LARGE;
   cb.nnz_all = nnz;
   return build_cone(c, ar, cb);
@@ -114,6 +116,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, 
     w.y = y;
     w.res = res;
     w.q = tvec;  // the epilogue's target scratch is free while the solver runs
+    w.rc = ar.get<double>(d);
     w.theta = ar.get<double>(p > 0 ? p : 1);
     w.ttry = ar.get<double>(p > 0 ? p : 1);
     w.g = ar.get<double>(p > 0 ? p : 1);
@@ -123,8 +126,16 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, 
     w.ldh = p | 1;
     w.H = ar.get<double>((uint32_t)(p > 0 ? p * w.ldh : 1));
     w.act = ar.get<uint8_t>(p > 0 ? p : 1);
+    uint8_t* lflag = ar.get<uint8_t>(p > 0 ? p : 1);
+    uint32_t* llist = ar.get<uint32_t>(p > 0 ? p : 1);
     if (ar.ovf) return ST_TOO_LARGE;
-    SolveResult r = solve_cone(c, v, w, max_iter, 1e-10);
+    for (int i = c.tid(); i < p; i += C::NT) lflag[i] = (uint8_t)((v.mhi[i] - v.mlo[i]) > kLongRow ? 1 : 0);
+    c.sync();
+    SolveView vv = v;
+    vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
+    vv.longrow = llist;
+    c.sync();
+    SolveResult r = solve_cone(c, vv, w, max_iter, 1e-10);
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
@@ -146,7 +157,9 @@ CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P,
   Arena ar;
   ar.init(smem, P.lds_bytes);
   ConeBuild cb;
+  CAVE_T0();
   int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
+  CAVE_ACC(0);
   int iters = 0;
   if (st == ST_OK) {
     const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
@@ -157,11 +170,14 @@ CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P,
       for (int k = c.tid(); k < d; k += C::NT) y[k] = P.pred ? P.sign * P.pred[b * d + k] : 0.f;
       c.sync();
       if (need_avg) compute_avg(c, cb, avg);
+      ar.release_top();  // build-phase temporaries (row tags, unit counts, pair scratch) are dead now
       SolveView v;
       v.d = d; v.p = cb.p; v.n_valid = cb.n_valid_proj;
       v.mlo = cb.mlo; v.mhi = cb.mhi; v.ecol = cb.ecol; v.eval = cb.eval; v.vkind = cb.vkind;
       v.cptr = cb.cptr; v.cvar = cb.cvar; v.cvalc = cb.cvalc; v.usign = cb.usign;
+      CAVE_ACC(1);
       st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+      CAVE_ACC(9);
     }
   }
   if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);
@@ -295,21 +311,22 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
 static inline uint32_t align8u(uint64_t x) { return (uint32_t)((x + 7u) & ~7ull); }
 static constexpr uint32_t kMaxLds = 160u * 1024u;
 
-// arena bytes whose size is known from (m, d, cap)
-static inline uint64_t fixed_bytes_dense(int64_t m, int64_t d, int64_t cap) {
-  uint64_t s = 0;
-  s += align8u(2 * cap) + align8u(4 * cap) + align8u(4 * (m + 1));          // ecol, eval, rptr
-  s += align8u(4 * d) + align8u(d) + align8u(m) + align8u(4 * (d + 1));     // ucnt, usign, rowtag, cptr
-  s += align8u(4 * d) * 3 + align8u(8 * d) * 2;                             // fill, y, avg, res, tvec
-  return s + 64;
-}
-
-static inline uint64_t var_bytes(int64_t rows_raw, int64_t p, int64_t nnzM) {
-  uint64_t s = 0;
-  s += 5 * align8u(4 * rows_raw) + 2 * align8u(rows_raw) + 2 * align8u(8 * rows_raw);  // vraw..vkind, hashes
-  s += align8u(2 * nnzM) + align8u(4 * nnzM);                                           // CSC
-  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + align8u(p);                    // theta..step, H, act
-  return s + 64;
+// Upper bound of the arena a dense launch needs, assuming at most `rows_raw` general rows,
+// `p` reduced rows and `nnzM` reduced non-zeros (the kernel reports ST_TOO_LARGE otherwise).
+static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int64_t rows_raw, int64_t p, int64_t nnzM) {
+  // bottom: persistent through the solve
+  uint64_t persist = align8u(2 * cap) + align8u(4 * cap) + align8u(d) + align8u(4 * (d + 1))   // ecol, eval, usign, cptr
+                     + 2 * align8u(4 * p) + align8u(p) + align8u(2 * nnzM) + align8u(4 * nnzM);  // mlo, mhi, vkind, CSC
+  // top: build-phase temporaries
+  uint64_t temps = align8u(4 * (m + 1)) + align8u(4 * d) + align8u(m)                 // rptr, ucnt, rowtag
+                   + 3 * align8u(4 * rows_raw) + align8u(rows_raw)                     // vraw, vnorm, twin, keep
+                   + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // hashes | fill
+  uint64_t vecs = 2 * align8u(4 * d);                                                 // y, avg
+  uint64_t solve = 3 * align8u(8 * d)                                                 // res, tvec/q, rc
+                   + 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, H, act, long rows
+  uint64_t build_peak = persist + temps + vecs;
+  uint64_t solve_peak = persist + vecs + solve;
+  return (build_peak > solve_peak ? build_peak : solve_peak) + 64;
 }
 
 static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes) {
@@ -317,10 +334,10 @@ static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap,
   int64_t cap = 4 * (m_max + d) + 256;
   if (cap > m_max * d) cap = m_max * d;
   if (cap < 64) cap = 64;
-  uint64_t need = fixed_bytes_dense(m_max, d, cap) + var_bytes(64, 32, cap * 6 / 10);
+  uint64_t need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10);
   while (need > kMaxLds && cap > 256) {
     cap = cap * 3 / 4;
-    need = fixed_bytes_dense(m_max, d, cap) + var_bytes(64, 32, cap * 6 / 10);
+    need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10);
   }
   if (need > kMaxLds) need = kMaxLds;
   if (nnz_cap) *nnz_cap = (int32_t)cap;
@@ -334,7 +351,7 @@ static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& l
   if (cap <= 0) cap = dcap;
   if (lds <= 0) {
     // honour a caller-supplied nnz_cap when deriving the arena size
-    uint64_t need = fixed_bytes_dense(m, d, cap) + var_bytes(64, 32, (int64_t)cap * 6 / 10);
+    uint64_t need = arena_bytes_dense(m, d, cap, 64, 32, (int64_t)cap * 6 / 10);
     lds = (int32_t)(need > kMaxLds ? kMaxLds : need);
   }
   return lds > 0 && (uint32_t)lds <= kMaxLds && cap > 0;
@@ -345,9 +362,9 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
   s += 2 * align8u(4 * (int64_t)max_rows) + align8u(max_rows);                           // mlo, mhi, vkind
   s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC
-  s += align8u(8 * d) * 2;                                                               // res, tvec
+  s += align8u(8 * d) * 3;                                                               // res, tvec, rc
   int64_t p = max_rows;
-  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + align8u(p) + 128;
+  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128;
   if (s > kMaxLds) return -1;
   return (int32_t)s;
 }

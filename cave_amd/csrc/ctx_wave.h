@@ -27,6 +27,7 @@ __device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A,
 
 struct WaveCtx {
   static constexpr int NT = 64;
+  static constexpr int TEAM = 4;         // lanes sharing one CSR row in gradient()
   static constexpr int SCAN_UNROLL = 8;  // 8 x 1 KiB dwordx4 loads in flight per wave
   __device__ __forceinline__ uint32_t scan_dense(const float* A, uint32_t n, uint32_t d, uint16_t* ecol, float* eval,
                                                  uint32_t* rowcnt, uint32_t cap) const {
@@ -34,23 +35,55 @@ struct WaveCtx {
   }
   static constexpr int PMAX = 64;  // largest reduced system solve_spd handles in registers
   int lane;
+#ifdef CAVE_STAMPS
+  unsigned long long st[16];
+#endif
   __device__ __forceinline__ int tid() const { return lane; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
 
+  // ---- wave-wide reductions / scans on the DPP crossbar (no LDS traffic, fixed summation tree)
+  template <int CTRL, int RM>
+  static __device__ __forceinline__ double dpp_f64(double old, double x) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, RM, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, RM, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  template <int CTRL, int RM>
+  static __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, RM, 0xf, false);
+  }
   __device__ __forceinline__ double reduce_sum(double v) const {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_f64<0xb1, 0xf>(0.0, v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4e, 0xf>(0.0, v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x114, 0xf>(0.0, v);  // row_shr:4
+    v += dpp_f64<0x118, 0xf>(0.0, v);  // row_shr:8
+    v += dpp_f64<0x142, 0xa>(0.0, v);  // row_bcast:15 -> rows 1,3
+    v += dpp_f64<0x143, 0xc>(0.0, v);  // row_bcast:31 -> rows 2,3
+    return readlane_f64(v, 63);
+  }
+  // sum over the TEAM = 4 lanes of a quad; every lane gets the result
+  __device__ __forceinline__ double team_reduce_sum(double v) const {
+    v += dpp_f64<0xb1, 0xf>(0.0, v);
+    v += dpp_f64<0x4e, 0xf>(0.0, v);
     return v;
   }
   __device__ __forceinline__ double reduce_max(double v) const {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_f64<0xb1, 0xf>(v, v));
+    v = fmax(v, dpp_f64<0x4e, 0xf>(v, v));
+    v = fmax(v, dpp_f64<0x114, 0xf>(v, v));
+    v = fmax(v, dpp_f64<0x118, 0xf>(v, v));
+    v = fmax(v, dpp_f64<0x142, 0xa>(v, v));
+    v = fmax(v, dpp_f64<0x143, 0xc>(v, v));
+    return readlane_f64(v, 63);
   }
   __device__ __forceinline__ uint32_t reduce_add_u32(uint32_t v) const {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_u32<0xb1, 0xf>(0u, v);
+    v += dpp_u32<0x4e, 0xf>(0u, v);
+    v += dpp_u32<0x114, 0xf>(0u, v);
+    v += dpp_u32<0x118, 0xf>(0u, v);
+    v += dpp_u32<0x142, 0xa>(0u, v);
+    v += dpp_u32<0x143, 0xc>(0u, v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
   }
   __device__ __forceinline__ void atomic_add_u32(uint32_t* p, uint32_t v) const { atomicAdd(p, v); }
   __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }  // ds_add_f64
@@ -62,13 +95,14 @@ struct WaveCtx {
       int i = base + lane;
       uint32_t v = (i < n) ? a[i] : 0u;
       uint32_t inc = v;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-      }
+      inc += dpp_u32<0x111, 0xf>(0u, inc);  // row_shr:1  (Hillis-Steele inside each 16-lane row)
+      inc += dpp_u32<0x112, 0xf>(0u, inc);  // row_shr:2
+      inc += dpp_u32<0x114, 0xf>(0u, inc);  // row_shr:4
+      inc += dpp_u32<0x118, 0xf>(0u, inc);  // row_shr:8
+      inc += dpp_u32<0x142, 0xa>(0u, inc);  // row_bcast:15 -> rows 1,3
+      inc += dpp_u32<0x143, 0xc>(0u, inc);  // row_bcast:31 -> rows 2,3
       if (i < n) a[i] = carry + inc - v;
-      carry += __shfl(inc, 63, 64);
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
     __syncthreads();
     return carry;
@@ -157,10 +191,15 @@ struct WaveCtx {
 // Stream one dense instance (n = m*d floats, row-major) and append its non-zeros
 // in row-major order to (ecol, eval); rowcnt[row] receives the per-row count.
 // Returns the number of non-zeros seen (entries beyond `cap` are counted, not stored).
-__device__ __forceinline__ void emit_entry(uint32_t pos, uint32_t f, float v, uint32_t d, uint16_t* ecol, float* eval,
-                                           uint32_t* rowcnt, uint32_t cap) {
-  uint32_t row = f / d;
-  uint32_t col = f - row * d;
+// Non-zeros are rare (a few per KiB for structured cones), so the per-entry work sits behind
+// one wave-uniform test per 1 KiB chunk and runs only in the lanes that own a non-zero.
+__device__ __forceinline__ void emit_entry(uint32_t pos, uint32_t f, float v, uint32_t d, double inv_d, uint16_t* ecol,
+                                           float* eval, uint32_t* rowcnt, uint32_t cap) {
+  // f / d without an integer divide: the fp64 estimate is within +-1 of the quotient for f < 2^32
+  uint32_t row = (uint32_t)((double)f * inv_d);
+  int32_t col = (int32_t)(f - row * d);
+  if (col < 0) { row -= 1u; col += (int32_t)d; }
+  else if (col >= (int32_t)d) { row += 1u; col -= (int32_t)d; }
   if (pos < cap) {
     ecol[pos] = (uint16_t)col;
     eval[pos] = v;
@@ -168,25 +207,31 @@ __device__ __forceinline__ void emit_entry(uint32_t pos, uint32_t f, float v, ui
   atomicAdd(&rowcnt[row], 1u);
 }
 
-__device__ __forceinline__ void scan_chunk1(float v, bool valid, uint32_t f, uint32_t d, uint32_t& cursor,
-                                            uint16_t* ecol, float* eval, uint32_t* rowcnt, uint32_t cap) {
+__device__ __forceinline__ void scan_chunk1(float v, bool valid, uint32_t f, uint32_t d, double inv_d,
+                                            uint32_t& cursor, uint16_t* ecol, float* eval, uint32_t* rowcnt,
+                                            uint32_t cap) {
   bool nz = valid && (v != 0.0f);
   uint64_t m = __ballot(nz);
   if (m == 0ull) return;
-  if (nz) emit_entry(cursor + mbcnt64(m), f, v, d, ecol, eval, rowcnt, cap);
+  if (nz) emit_entry(cursor + mbcnt64(m), f, v, d, inv_d, ecol, eval, rowcnt, cap);
   cursor += (uint32_t)__popcll(m);
 }
 
-__device__ __forceinline__ void scan_chunk4(float4 v, uint32_t f, uint32_t d, uint32_t& cursor, uint16_t* ecol,
-                                            float* eval, uint32_t* rowcnt, uint32_t cap) {
+__device__ __forceinline__ void scan_chunk4(float4 v, uint32_t f, uint32_t d, double inv_d, uint32_t& cursor,
+                                            uint16_t* ecol, float* eval, uint32_t* rowcnt, uint32_t cap) {
   bool n0 = v.x != 0.0f, n1 = v.y != 0.0f, n2 = v.z != 0.0f, n3 = v.w != 0.0f;
   uint64_t m0 = __ballot(n0), m1 = __ballot(n1), m2 = __ballot(n2), m3 = __ballot(n3);
   if ((m0 | m1 | m2 | m3) == 0ull) return;
+  // lane-major, then component order == flat (row-major) order
   uint32_t pos = cursor + mbcnt64(m0) + mbcnt64(m1) + mbcnt64(m2) + mbcnt64(m3);
-  if (n0) { emit_entry(pos, f, v.x, d, ecol, eval, rowcnt, cap); pos++; }
-  if (n1) { emit_entry(pos, f + 1, v.y, d, ecol, eval, rowcnt, cap); pos++; }
-  if (n2) { emit_entry(pos, f + 2, v.z, d, ecol, eval, rowcnt, cap); pos++; }
-  if (n3) { emit_entry(pos, f + 3, v.w, d, ecol, eval, rowcnt, cap); pos++; }
+  uint32_t nzm = (uint32_t)n0 | ((uint32_t)n1 << 1) | ((uint32_t)n2 << 2) | ((uint32_t)n3 << 3);
+  while (nzm) {
+    int ci = __ffs((int)nzm) - 1;
+    nzm &= nzm - 1u;
+    float val = ci == 0 ? v.x : (ci == 1 ? v.y : (ci == 2 ? v.z : v.w));
+    emit_entry(pos, f + (uint32_t)ci, val, d, inv_d, ecol, eval, rowcnt, cap);
+    pos++;
+  }
   cursor += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
 }
 
@@ -194,13 +239,14 @@ template <int U>
 __device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A, uint32_t n, uint32_t d, int lane,
                                                     uint16_t* ecol, float* eval, uint32_t* rowcnt, uint32_t cap) {
   uint32_t cursor = 0;
+  const double inv_d = 1.0 / (double)d;
   // head: elements before the first 16-byte boundary
   uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)A & 15u)) & 15u) >> 2);
   if (head > n) head = n;
   if (head) {
     bool valid = (uint32_t)lane < head;
     float v = valid ? A[lane] : 0.0f;
-    scan_chunk1(v, valid, (uint32_t)lane, d, cursor, ecol, eval, rowcnt, cap);
+    scan_chunk1(v, valid, (uint32_t)lane, d, inv_d, cursor, ecol, eval, rowcnt, cap);
   }
   const float4* __restrict__ A4 = reinterpret_cast<const float4*>(A + head);
   const uint32_t n4 = (n - head) >> 2;
@@ -216,7 +262,7 @@ __device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       uint32_t i = t + (uint32_t)u * 64u + (uint32_t)lane;
-      scan_chunk4(buf[u], head + 4u * i, d, cursor, ecol, eval, rowcnt, cap);
+      scan_chunk4(buf[u], head + 4u * i, d, inv_d, cursor, ecol, eval, rowcnt, cap);
     }
   }
   // tail
@@ -224,7 +270,7 @@ __device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A,
   if (done < n) {
     bool valid = done + (uint32_t)lane < n;
     float v = valid ? A[done + lane] : 0.0f;
-    scan_chunk1(v, valid, done + (uint32_t)lane, d, cursor, ecol, eval, rowcnt, cap);
+    scan_chunk1(v, valid, done + (uint32_t)lane, d, inv_d, cursor, ecol, eval, rowcnt, cap);
   }
   return cursor;
 }

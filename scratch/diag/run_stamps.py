@@ -1,0 +1,22 @@
+"""Diagnostic: per-phase cycle shares of cone_dense_kernel (stamps build; never quote its run time)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from cave_amd import _lib, synth
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcave_hip_stamps.so")
+from cave_amd.qpsolver import cone_op_dense
+lib = _lib.load()
+ctrs, costs, _ = synth.tsp_batch(20, 1024, seed=0)
+c = torch.tensor(ctrs, device="cuda"); p = torch.tensor(costs, device="cuda")
+names = ["scan+build", "load y/avg", "grad+pgn", "hessian", "inner misc (rhs/ratio/matvec/update)", "solve_spd (GJ)", "ls setup + gather q", "ls dphi loop + theta update", "gather r + f", "epilogue(+solve total tail)", "  scan only", "  classify rows", "  pairing", "  var list + CSC"]
+for mode in (0, 2):
+    outs = ("proj","rnorm") if mode==0 else ("loss","grad")
+    for _ in range(3): cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs)
+    o = cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs)
+    buf = (C.c_ulonglong * (16*1024))()
+    lib.cave_hip_debug_stamps(buf, 1024)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16).astype(np.float64)
+    mean = a.mean(0); tot = mean[0] + mean[1] + mean[9]
+    print(f"mode {mode}: iters mean {o['iters'].float().mean():.2f}; cycles/instance {tot:.0f} = {tot/2.4e3:.1f} us @2.4GHz")
+    for i, n in enumerate(names):
+        print(f"  {n:45s} {mean[i]:10.0f}  {100*mean[i]/tot:5.1f}%")

@@ -11,6 +11,8 @@ namespace cave {
 
 struct SerialCtx {
   static constexpr int NT = 1;
+  static constexpr int TEAM = 1;
+  double team_reduce_sum(double v) const { return v; }
   static constexpr int PMAX = 64;
   int tid() const { return 0; }
   void sync() const {}
