@@ -115,6 +115,7 @@ struct SolveWork {
   double* step;    // [p]  Newton step of one inner round
   double* H;       // [p*ldh]
   uint8_t* act;    // [p]
+  uint8_t* dflag;  // [d]  coordinates currently counted in H
   int ldh;
 };
 

@@ -47,6 +47,8 @@ struct ConeBuild {
   int n_valid_avg;
 };
 
+static constexpr uint32_t kHashPrefix = 12;
+
 // Classify rows, detect +a/-a pairs, build CSR/CSC of the reduced rows.
 // Pre: cb.ecol/eval/rptr hold the scan output (rptr = per-row counts, m+1 entries,
 // last = 0), cb.nnz_all set.  Returns ST_OK or ST_TOO_LARGE.
@@ -114,17 +116,25 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   for (int i = c.tid(); i < pr; i += NT) {
     uint32_t r = cb.vraw[i];
     uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
-    uint64_t a = 0x1234567ull, b = 0x1234567ull;
+    // signature of the row and of its negation: length + the first kHashPrefix entries (two 32-bit
+    // FNV-1a streams each).  Candidates are verified entry by entry below, so a prefix is enough.
+    uint32_t a0 = 0x811c9dc5u ^ (hi - lo), a1 = 0x9747b28cu + (hi - lo), b0 = a0, b1 = a1;
     float s2 = 0.f;
     for (uint32_t e = lo; e < hi; ++e) {
-      uint32_t u = f2u(cb.eval[e]);
-      uint64_t col = cb.ecol[e];
-      a = mix64(a, (col << 32) | u);
-      b = mix64(b, (col << 32) | (u ^ 0x80000000u));
-      s2 += cb.eval[e] * cb.eval[e];
+      float val = cb.eval[e];
+      s2 += val * val;
+      if (e - lo < kHashPrefix) {
+        uint32_t u = f2u(val), col = cb.ecol[e];
+        uint32_t xp = u ^ (col * 0x9e3779b1u), xn = (u ^ 0x80000000u) ^ (col * 0x9e3779b1u);
+        // xor-shift after each multiply so the sign bit (bit 31) reaches the low bits
+        a0 = (a0 ^ xp) * 0x01000193u; a0 ^= a0 >> 15;
+        a1 = (a1 + xp) * 0x85ebca6bu; a1 ^= a1 >> 13;
+        b0 = (b0 ^ xn) * 0x01000193u; b0 ^= b0 >> 15;
+        b1 = (b1 + xn) * 0x85ebca6bu; b1 ^= b1 >> 13;
+      }
     }
-    hp[i] = a;
-    hn[i] = b;
+    hp[i] = ((uint64_t)a1 << 32) | a0;
+    hn[i] = ((uint64_t)b1 << 32) | b0;
     cb.vnorm[i] = sqrtf(s2);
   }
   c.sync();
@@ -337,6 +347,9 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
   c.sync();
   double f = refresh_clipped(c, v, r, rc);
   const int ldh = w.ldh;
+  for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+  for (int k = c.tid(); k < d; k += NT) w.dflag[k] = 0;
+  c.sync();
   double g0n = 0.0;
   double reg_rel = 1e-10;  // Levenberg shift relative to max diag(H); raised when a step stalls
   bool converged = (p == 0);
@@ -358,16 +371,18 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
 #endif
     CAVE_ACC(2);
     if (!(pgn > tol * g0n) || f <= 1e-30 * yy) { converged = true; break; }
-    // generalised Hessian H = M D M^T, D = [Pi(r) != 0], by column outer products
-    for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
-    c.sync();
+    // generalised Hessian H = M D M^T, D = [Pi(r) != 0]: rank-one updates +-m_k m_k^T for the
+    // coordinates whose activity flipped since the previous iteration (all active ones at it 0)
     for (int k = c.tid(); k < d; k += NT) {
-      if (rc[k] == 0.0) continue;
+      const uint8_t on = (uint8_t)(rc[k] != 0.0);
+      if (on == w.dflag[k]) continue;
+      w.dflag[k] = on;
+      const double sg = on ? 1.0 : -1.0;
       uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
       for (uint32_t e1 = lo; e1 < hi; ++e1) {
         uint32_t a = v.cvar[e1];
-        double va = (double)v.cvalc[e1];
-        c.atomic_add_f64(&w.H[a * ldh + a], va * va);
+        double va = sg * (double)v.cvalc[e1];
+        c.atomic_add_f64(&w.H[a * ldh + a], va * (double)v.cvalc[e1]);
         for (uint32_t e2 = lo; e2 < e1; ++e2) {
           uint32_t b = v.cvar[e2];
           double vv = va * (double)v.cvalc[e2];
@@ -492,7 +507,11 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
     }
     c.sync();
     CAVE_ACC(7);
-    gather_mt(c, v, w.y, theta, -1.0, r);  // fresh residual (no drift)
+    if ((it & 7) == 7) gather_mt(c, v, w.y, theta, -1.0, r);  // periodic fresh residual bounds the drift
+    else {
+      for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
+      c.sync();
+    }
     double fn = refresh_clipped(c, v, r, rc);
     CAVE_ACC(8);
     // An exact line search along the Newton direction that no longer lowers f beyond
@@ -509,7 +528,11 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
       reg_rel *= 1e3;
     } else if (reg_rel > 1e-10) reg_rel *= 0.1;
   }
-  // leave the clipped residual behind for the epilogue
+  // final residual straight from theta (the iteration updated r incrementally), clipped for the epilogue
+  if (p > 0) {
+    gather_mt(c, v, w.y, theta, -1.0, r);
+    f = refresh_clipped(c, v, r, rc);
+  }
   for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];
   c.sync();
   if (!converged) out.status = ST_NOT_CONVERGED;

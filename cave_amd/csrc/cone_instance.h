@@ -81,16 +81,31 @@ CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, i
   cb.d = d;
   cb.m = m;
   cb.ecol = ar.get<uint16_t>(cap);
-  cb.eval = ar.get<float>(cap);
+  cb.eval = ar.get<float>(cap + 64u);  // +64: per-lane dump slots of the branch-free scan
   cb.rptr = ar.get_top<uint32_t>((uint32_t)m + 1u);
+  const uint32_t top_mark = ar.top;
+  uint32_t* eflat = ar.get_top<uint32_t>(cap + 64u);  // flat indices of the non-zeros; dead after finish_scan
   if (ar.ovf) return ST_TOO_LARGE;
   for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
   c.sync();
   CAVE_T0();
-  uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, (uint32_t)d, cb.ecol, cb.eval, cb.rptr, cap);
+  uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, eflat, cb.eval, cap);
   c.sync();
   CAVE_ACC(10);
   if (nnz > cap) return ST_TOO_LARGE;
+  // row / column of every entry (f = row*d + col) and the per-row counts
+  const double inv_d = 1.0 / (double)d;
+  for (uint32_t e = c.tid(); e < nnz; e += C::NT) {
+    const uint32_t f = eflat[e];
+    uint32_t row = (uint32_t)((double)f * inv_d);  // within +-1 of f / d for f < 2^32
+    int32_t col = (int32_t)(f - row * (uint32_t)d);
+    if (col < 0) { row -= 1u; col += d; }
+    else if (col >= d) { row += 1u; col -= d; }
+    cb.ecol[e] = (uint16_t)col;
+    c.atomic_add_u32(&cb.rptr[row], 1u);
+  }
+  c.sync();
+  ar.top = top_mark;  // release eflat
   cb.nnz_all = nnz;
   return build_cone(c, ar, cb);
 }
@@ -117,6 +132,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, 
     w.res = res;
     w.q = tvec;  // the epilogue's target scratch is free while the solver runs
     w.rc = ar.get<double>(d);
+    w.dflag = ar.get<uint8_t>(d);
     w.theta = ar.get<double>(p > 0 ? p : 1);
     w.ttry = ar.get<double>(p > 0 ? p : 1);
     w.g = ar.get<double>(p > 0 ? p : 1);
@@ -315,15 +331,17 @@ static constexpr uint32_t kMaxLds = 160u * 1024u;
 // `p` reduced rows and `nnzM` reduced non-zeros (the kernel reports ST_TOO_LARGE otherwise).
 static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int64_t rows_raw, int64_t p, int64_t nnzM) {
   // bottom: persistent through the solve
-  uint64_t persist = align8u(2 * cap) + align8u(4 * cap) + align8u(d) + align8u(4 * (d + 1))   // ecol, eval, usign, cptr
+  uint64_t persist = align8u(2 * cap) + align8u(4 * cap + 256) + align8u(d) + align8u(4 * (d + 1))   // ecol, eval, usign, cptr
                      + 2 * align8u(4 * p) + align8u(p) + align8u(2 * nnzM) + align8u(4 * nnzM);  // mlo, mhi, vkind, CSC
   // top: build-phase temporaries
+  uint64_t scan_temps = align8u(4 * (m + 1)) + align8u(4 * cap + 256);                // rptr, eflat (scan only)
   uint64_t temps = align8u(4 * (m + 1)) + align8u(4 * d) + align8u(m)                 // rptr, ucnt, rowtag
                    + 3 * align8u(4 * rows_raw) + align8u(rows_raw)                     // vraw, vnorm, twin, keep
                    + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // hashes | fill
   uint64_t vecs = 2 * align8u(4 * d);                                                 // y, avg
-  uint64_t solve = 3 * align8u(8 * d)                                                 // res, tvec/q, rc
+  uint64_t solve = 3 * align8u(8 * d) + align8u(d)                                    // res, tvec/q, rc, dflag
                    + 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, H, act, long rows
+  if (scan_temps > temps) temps = scan_temps;
   uint64_t build_peak = persist + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64;
@@ -362,7 +380,7 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
   s += 2 * align8u(4 * (int64_t)max_rows) + align8u(max_rows);                           // mlo, mhi, vkind
   s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC
-  s += align8u(8 * d) * 3;                                                               // res, tvec, rc
+  s += align8u(8 * d) * 3 + align8u(d);                                                  // res, tvec, rc, dflag
   int64_t p = max_rows;
   s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128;
   if (s > kMaxLds) return -1;

@@ -22,16 +22,16 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 }
 
 template <int U>
-__device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A, uint32_t n, uint32_t d, int lane,
-                                                    uint16_t* ecol, float* eval, uint32_t* rowcnt, uint32_t cap);
+__device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A, uint32_t n, int lane, uint32_t* eflat,
+                                                    float* eval, uint32_t cap);
 
 struct WaveCtx {
   static constexpr int NT = 64;
   static constexpr int TEAM = 4;         // lanes sharing one CSR row in gradient()
   static constexpr int SCAN_UNROLL = 8;  // 8 x 1 KiB dwordx4 loads in flight per wave
-  __device__ __forceinline__ uint32_t scan_dense(const float* A, uint32_t n, uint32_t d, uint16_t* ecol, float* eval,
-                                                 uint32_t* rowcnt, uint32_t cap) const {
-    return scan_dense_wave<SCAN_UNROLL>(A, n, d, lane, ecol, eval, rowcnt, cap);
+  __device__ __forceinline__ uint32_t scan_dense(const float* A, uint32_t n, uint32_t* eflat, float* eval,
+                                                 uint32_t cap) const {
+    return scan_dense_wave<SCAN_UNROLL>(A, n, lane, eflat, eval, cap);
   }
   static constexpr int PMAX = 64;  // largest reduced system solve_spd handles in registers
   int lane;
@@ -181,88 +181,97 @@ struct WaveCtx {
                                             double reg_rel, double* dv) const {
     if (p <= 8) solve_spd_regs<8>(H, ldh, g, act, p, reg_rel, dv);
     else if (p <= 16) solve_spd_regs<16>(H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 20) solve_spd_regs<20>(H, ldh, g, act, p, reg_rel, dv);
     else if (p <= 24) solve_spd_regs<24>(H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 28) solve_spd_regs<28>(H, ldh, g, act, p, reg_rel, dv);
     else if (p <= 32) solve_spd_regs<32>(H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 40) solve_spd_regs<40>(H, ldh, g, act, p, reg_rel, dv);
     else if (p <= 48) solve_spd_regs<48>(H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 56) solve_spd_regs<56>(H, ldh, g, act, p, reg_rel, dv);
     else solve_spd_regs<64>(H, ldh, g, act, p, reg_rel, dv);
   }
 };
 
-// Stream one dense instance (n = m*d floats, row-major) and append its non-zeros
-// in row-major order to (ecol, eval); rowcnt[row] receives the per-row count.
-// Returns the number of non-zeros seen (entries beyond `cap` are counted, not stored).
-// Non-zeros are rare (a few per KiB for structured cones), so the per-entry work sits behind
-// one wave-uniform test per 1 KiB chunk and runs only in the lanes that own a non-zero.
-__device__ __forceinline__ void emit_entry(uint32_t pos, uint32_t f, float v, uint32_t d, double inv_d, uint16_t* ecol,
-                                           float* eval, uint32_t* rowcnt, uint32_t cap) {
-  // f / d without an integer divide: the fp64 estimate is within +-1 of the quotient for f < 2^32
-  uint32_t row = (uint32_t)((double)f * inv_d);
-  int32_t col = (int32_t)(f - row * d);
-  if (col < 0) { row -= 1u; col += (int32_t)d; }
-  else if (col >= (int32_t)d) { row += 1u; col -= (int32_t)d; }
-  if (pos < cap) {
-    ecol[pos] = (uint16_t)col;
-    eval[pos] = v;
-  }
-  atomicAdd(&rowcnt[row], 1u);
-}
-
-__device__ __forceinline__ void scan_chunk1(float v, bool valid, uint32_t f, uint32_t d, double inv_d,
-                                            uint32_t& cursor, uint16_t* ecol, float* eval, uint32_t* rowcnt,
-                                            uint32_t cap) {
+// Stream one dense instance (n floats, row-major) and append its non-zeros, in flat (row-major)
+// order, as (flat index, value) pairs to (eflat, eval).  Returns the number of non-zeros seen
+// (entries beyond `cap` are counted, not stored; eflat/eval must have cap + 64 slots, the last 64
+// are per-lane dump slots).  Row/column are derived afterwards, once per
+// entry (cone_instance.h finish_scan), so the per-KiB streaming loop stays short: 4 compares,
+// a wave-uniform "anything here?" test, ordered slot computation with mbcnt, two LDS stores.
+__device__ __forceinline__ void scan_chunk1(float v, bool valid, uint32_t f, uint32_t& cursor, uint32_t* eflat,
+                                            float* eval, uint32_t cap) {
   bool nz = valid && (v != 0.0f);
   uint64_t m = __ballot(nz);
   if (m == 0ull) return;
-  if (nz) emit_entry(cursor + mbcnt64(m), f, v, d, inv_d, ecol, eval, rowcnt, cap);
+  uint32_t pos = cursor + mbcnt64(m);
+  if (nz && pos < cap) { eflat[pos] = f; eval[pos] = v; }
   cursor += (uint32_t)__popcll(m);
 }
 
-__device__ __forceinline__ void scan_chunk4(float4 v, uint32_t f, uint32_t d, double inv_d, uint32_t& cursor,
-                                            uint16_t* ecol, float* eval, uint32_t* rowcnt, uint32_t cap) {
+__device__ __forceinline__ void scan_chunk4(float4 v, uint32_t f, uint32_t& cursor, uint32_t* eflat, float* eval,
+                                            uint32_t cap) {
   bool n0 = v.x != 0.0f, n1 = v.y != 0.0f, n2 = v.z != 0.0f, n3 = v.w != 0.0f;
   uint64_t m0 = __ballot(n0), m1 = __ballot(n1), m2 = __ballot(n2), m3 = __ballot(n3);
   if ((m0 | m1 | m2 | m3) == 0ull) return;
-  // lane-major, then component order == flat (row-major) order
-  uint32_t pos = cursor + mbcnt64(m0) + mbcnt64(m1) + mbcnt64(m2) + mbcnt64(m3);
-  uint32_t nzm = (uint32_t)n0 | ((uint32_t)n1 << 1) | ((uint32_t)n2 << 2) | ((uint32_t)n3 << 3);
-  while (nzm) {
-    int ci = __ffs((int)nzm) - 1;
-    nzm &= nzm - 1u;
-    float val = ci == 0 ? v.x : (ci == 1 ? v.y : (ci == 2 ? v.z : v.w));
-    emit_entry(pos, f + (uint32_t)ci, val, d, inv_d, ecol, eval, rowcnt, cap);
-    pos++;
-  }
+  // lane-major, then component order == flat (row-major) order.  Branch-free: components that are
+  // zero (or beyond the capacity) go to this lane's dump slot cap + lane (a shared slot would
+  // serialise the 60-odd idle lanes on one LDS bank).
+  const uint32_t p0 = cursor + mbcnt64(m0) + mbcnt64(m1) + mbcnt64(m2) + mbcnt64(m3);
+  const uint32_t p1 = p0 + (uint32_t)n0, p2 = p1 + (uint32_t)n1, p3 = p2 + (uint32_t)n2;
+  const uint32_t dump = cap + (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // cap + lane
+  const uint32_t i0 = (n0 && p0 < cap) ? p0 : dump, i1 = (n1 && p1 < cap) ? p1 : dump;
+  const uint32_t i2 = (n2 && p2 < cap) ? p2 : dump, i3 = (n3 && p3 < cap) ? p3 : dump;
+  eflat[i0] = f;      eval[i0] = v.x;
+  eflat[i1] = f + 1u; eval[i1] = v.y;
+  eflat[i2] = f + 2u; eval[i2] = v.z;
+  eflat[i3] = f + 3u; eval[i3] = v.w;
   cursor += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
 }
 
 template <int U>
-__device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A, uint32_t n, uint32_t d, int lane,
-                                                    uint16_t* ecol, float* eval, uint32_t* rowcnt, uint32_t cap) {
+__device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A, uint32_t n, int lane, uint32_t* eflat,
+                                                    float* eval, uint32_t cap) {
   uint32_t cursor = 0;
-  const double inv_d = 1.0 / (double)d;
   // head: elements before the first 16-byte boundary
   uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)A & 15u)) & 15u) >> 2);
   if (head > n) head = n;
   if (head) {
     bool valid = (uint32_t)lane < head;
     float v = valid ? A[lane] : 0.0f;
-    scan_chunk1(v, valid, (uint32_t)lane, d, inv_d, cursor, ecol, eval, rowcnt, cap);
+    scan_chunk1(v, valid, (uint32_t)lane, cursor, eflat, eval, cap);
   }
   const float4* __restrict__ A4 = reinterpret_cast<const float4*>(A + head);
   const uint32_t n4 = (n - head) >> 2;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // main: U x 1 KiB in flight per wave
-  for (uint32_t t = 0; t < n4; t += 64u * U) {
-    float4 buf[U];
+  // main: batches of U x 1 KiB per wave, software-pipelined two deep (the next batch's loads are
+  // in flight while the current one is scanned), so HBM latency overlaps the ballot/emit work
+  const uint32_t step = 64u * U;
+  float4 bufA[U], bufB[U];
+  auto load_batch = [&](float4* buf, uint32_t t) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      // unconditional 16-byte load from a clamped index (a select around the load would be split
+      // into four predicated dword loads); out-of-range chunks are zeroed when scanned
       uint32_t i = t + (uint32_t)u * 64u + (uint32_t)lane;
-      buf[u] = (i < n4) ? A4[i] : z4;
+      buf[u] = A4[i < n4 ? i : n4 - 1u];
     }
+  };
+  auto scan_batch = [&](const float4* buf, uint32_t t) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       uint32_t i = t + (uint32_t)u * 64u + (uint32_t)lane;
-      scan_chunk4(buf[u], head + 4u * i, d, inv_d, cursor, ecol, eval, rowcnt, cap);
+      float4 v = buf[u];
+      if (i >= n4) v = z4;
+      scan_chunk4(v, head + 4u * i, cursor, eflat, eval, cap);
+    }
+  };
+  if (n4 > 0) load_batch(bufA, 0);
+  for (uint32_t t = 0; t < n4; t += 2u * step) {
+    if (t + step < n4) load_batch(bufB, t + step);
+    scan_batch(bufA, t);
+    if (t + step < n4) {
+      if (t + 2u * step < n4) load_batch(bufA, t + 2u * step);
+      scan_batch(bufB, t + step);
     }
   }
   // tail
@@ -270,7 +279,7 @@ __device__ __forceinline__ uint32_t scan_dense_wave(const float* __restrict__ A,
   if (done < n) {
     bool valid = done + (uint32_t)lane < n;
     float v = valid ? A[done + lane] : 0.0f;
-    scan_chunk1(v, valid, done + (uint32_t)lane, d, inv_d, cursor, ecol, eval, rowcnt, cap);
+    scan_chunk1(v, valid, done + (uint32_t)lane, cursor, eflat, eval, cap);
   }
   return cursor;
 }

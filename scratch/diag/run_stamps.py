@@ -20,3 +20,4 @@ for mode in (0, 2):
     print(f"mode {mode}: iters mean {o['iters'].float().mean():.2f}; cycles/instance {tot:.0f} = {tot/2.4e3:.1f} us @2.4GHz")
     for i, n in enumerate(names):
         print(f"  {n:45s} {mean[i]:10.0f}  {100*mean[i]/tot:5.1f}%")
+    print(f"  whole instance: {mean[14]:.0f} memtime ticks in {mean[15]/100:.1f} us (memrealtime) -> {mean[14]/(mean[15]/100)/1e3:.3f} GHz")

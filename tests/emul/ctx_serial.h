@@ -36,15 +36,12 @@ struct SerialCtx {
     for (int i = 0; i < n; ++i) if (f[i]) out[c++] = (uint32_t)i;
     return c;
   }
-  uint32_t scan_dense(const float* A, uint32_t n, uint32_t d, uint16_t* ecol, float* eval, uint32_t* rowcnt,
-                      uint32_t cap) const {
+  uint32_t scan_dense(const float* A, uint32_t n, uint32_t* eflat, float* eval, uint32_t cap) const {
     uint32_t cur = 0;
     for (uint32_t f = 0; f < n; ++f) {
       float v = A[f];
       if (v != 0.0f) {
-        uint32_t row = f / d;
-        if (cur < cap) { ecol[cur] = (uint16_t)(f - row * d); eval[cur] = v; }
-        rowcnt[row] += 1;
+        if (cur < cap) { eflat[cur] = f; eval[cur] = v; }
         cur++;
       }
     }
