@@ -18,7 +18,8 @@ _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libcave_hip.so")
 _SOURCES = [
     os.path.join(_HERE, "csrc", n)
-    for n in ("cave_hip.hip", "cone_common.h", "cone_core.h", "cone_instance.h", "ctx_wave.h")
+    for n in ("cave_hip.hip", "cone_common.h", "cone_core.h", "cone_instance.h", "wave_prims.h", "ctx_wave.h",
+              "ctx_block.h")
 ] + [os.path.join(_ROOT, "include", "cave_hip.h")]
 
 # status / mode constants (include/cave_hip.h)
@@ -81,11 +82,11 @@ def load_library() -> C.CDLL:
         getattr(lib, name)  # AttributeError here = ABI drift between header and library
     i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
     lib.cave_hip_default_limits.argtypes = [i64, i64, C.POINTER(i32), C.POINTER(i32)]
-    lib.cave_hip_cone_dense.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i32, i32,
+    lib.cave_hip_cone_dense.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i32, i32, i32,
                                         vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.cave_hip_pack_count.argtypes = [vp, i64, i64, i64, i32, i32, vp, vp, vp, vp]
-    lib.cave_hip_pack_fill.argtypes = [vp, i64, i64, i64, i32, i32, C.POINTER(Store), i64, vp, vp]
-    lib.cave_hip_cone_packed.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32,
+    lib.cave_hip_pack_count.argtypes = [vp, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp]
+    lib.cave_hip_pack_fill.argtypes = [vp, i64, i64, i64, i32, i32, i32, C.POINTER(Store), i64, vp, vp]
+    lib.cave_hip_cone_packed.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32, i32,
                                          vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cave_hip_packed_lds_bytes.argtypes = [i64, i32, i32]
     for name in ("cave_hip_default_limits", "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill",

@@ -16,6 +16,7 @@
 #include "cone_common.h"
 #include "cone_core.h"
 #include "ctx_wave.h"
+#include "ctx_block.h"
 #include "cone_instance.h"
 
 namespace cave {
@@ -24,10 +25,18 @@ namespace cave {
 __device__ unsigned long long g_stamp_buf[16 * 8192];
 #endif
 
-__global__ __launch_bounds__(64) void cone_dense_kernel(DenseParams P) {
+using Ctx1 = WaveCtx;      // one wave per instance, reduced systems up to 64 rows
+using Ctx4 = BlockCtx<4>;  // 4-wave workgroup per instance, reduced systems up to 32 rows
+
+// launch bounds: NT threads; for the 4-wave context ask for 4 waves per SIMD (= 4 workgroups per CU,
+// the residency LDS allows), which caps the kernel at 128 VGPRs
+#define CAVE_BOUNDS(C) __launch_bounds__(C::NT, (C::NT == 64 ? 1 : 4))
+
+template <class C>
+__global__ CAVE_BOUNDS(C) void cone_dense_kernel(DenseParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  WaveCtx c;
-  c.lane = (int)threadIdx.x;
+  C c;
+  c.init(smem);
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
 #ifdef CAVE_STAMPS
     for (int i = 0; i < 16; ++i) c.st[i] = 0;
@@ -37,26 +46,28 @@ __global__ __launch_bounds__(64) void cone_dense_kernel(DenseParams P) {
 #ifdef CAVE_STAMPS
     c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
     c.st[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
-    if (c.lane == 0 && b < 8192) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
+    if (c.tid() == 0 && b < 8192) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
 #endif
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(64) void cone_pack_kernel(PackParams P) {
+template <class C>
+__global__ CAVE_BOUNDS(C) void cone_pack_kernel(PackParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  WaveCtx c;
-  c.lane = (int)threadIdx.x;
+  C c;
+  c.init(smem);
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
     run_pack_instance(c, smem, P, b);
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(64) void cone_packed_kernel(PackedParams P) {
+template <class C>
+__global__ CAVE_BOUNDS(C) void cone_packed_kernel(PackedParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  WaveCtx c;
-  c.lane = (int)threadIdx.x;
+  C c;
+  c.init(smem);
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
     run_packed_instance(c, smem, P, b);
     __syncthreads();
@@ -78,6 +89,29 @@ static hipError_t ensure_lds(K kernel, uint32_t bytes) {
   if (bytes <= 48u * 1024u) return hipSuccess;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)bytes);
+}
+
+// launch kernel<Ctx4> or kernel<Ctx1> on B workgroups
+#define CAVE_LAUNCH(KERNEL, WAVES, B, LDS, STREAM, PARAMS, WHAT)                                              \
+  do {                                                                                                         \
+    hipError_t e_;                                                                                             \
+    unsigned grid_ = (unsigned)((B) < (int64_t)1 << 30 ? (B) : (int64_t)1 << 30);                              \
+    if ((WAVES) == 1) {                                                                                        \
+      e_ = ensure_lds(KERNEL<Ctx1>, (uint32_t)(LDS));                                                          \
+      if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                   \
+      hipLaunchKernelGGL(KERNEL<Ctx1>, dim3(grid_), dim3(Ctx1::NT), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS); \
+    } else {                                                                                                   \
+      e_ = ensure_lds(KERNEL<Ctx4>, (uint32_t)(LDS));                                                          \
+      if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                   \
+      hipLaunchKernelGGL(KERNEL<Ctx4>, dim3(grid_), dim3(Ctx4::NT), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS); \
+    }                                                                                                          \
+    e_ = hipGetLastError();                                                                                    \
+    if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "launch " WHAT, e_);                                      \
+  } while (0)
+
+static bool waves_ok(int32_t& waves) {
+  if (waves == 0) waves = 4;
+  return waves == 1 || waves == 4;
 }
 
 }  // namespace cave
@@ -113,8 +147,8 @@ int32_t cave_hip_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int3
 
 int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d, int32_t mode,
                             float sign, float inner_ratio, int32_t max_iter, int32_t nnz_cap, int32_t lds_bytes,
-                            float* proj, float* rnorm, float* target, float* loss, float* grad, int32_t* status,
-                            int32_t* iters, void* stream) {
+                            int32_t waves, float* proj, float* rnorm, float* target, float* loss, float* grad,
+                            int32_t* status, int32_t* iters, void* stream) {
   if (B < 0 || m_max < 0 || d <= 0 || d > 65535) return fail(CAVE_E_INVALID, "cone_dense: bad shape (need 0 < d <= 65535)");
   if (m_max * d >= (int64_t)1 << 32) return fail(CAVE_E_INVALID, "cone_dense: m_max*d must be < 2^32");
   if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense: bad mode");
@@ -122,58 +156,48 @@ int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int
   if (!ctrs && m_max > 0) return fail(CAVE_E_INVALID, "cone_dense: ctrs is null");
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense: pred is null");
   if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "cone_dense: bad nnz_cap / lds_bytes");
-  hipError_t e = ensure_lds(cone_dense_kernel, (uint32_t)lds_bytes);
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(cone_dense_kernel)", e);
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_dense: waves must be 0, 1 or 4");
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
   P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
-  unsigned grid = (unsigned)(B < (int64_t)1 << 30 ? B : (int64_t)1 << 30);
-  hipLaunchKernelGGL(cone_dense_kernel, dim3(grid), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, P);
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch cone_dense_kernel", e);
+  CAVE_LAUNCH(cone_dense_kernel, waves, B, lds_bytes, stream, P, "cone_dense_kernel");
   return CAVE_OK;
 }
 
 int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t d, int32_t nnz_cap, int32_t lds_bytes,
-                            int32_t* n_rows, int32_t* n_nnz, int32_t* status, void* stream) {
+                            int32_t waves, int32_t* n_rows, int32_t* n_nnz, int32_t* status, void* stream) {
   if (B < 0 || m_max < 0 || d <= 0 || d > 65535 || m_max * d >= (int64_t)1 << 32)
     return fail(CAVE_E_INVALID, "pack_count: bad shape");
   if (B == 0) return CAVE_OK;
   if (!ctrs || !n_rows || !n_nnz) return fail(CAVE_E_INVALID, "pack_count: null pointer");
   if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "pack_count: bad limits");
-  hipError_t e = ensure_lds(cone_pack_kernel, (uint32_t)lds_bytes);
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(cone_pack_kernel)", e);
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_count: waves must be 0, 1 or 4");
   PackParams P;
   memset(&P, 0, sizeof(P));
   P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
   P.n_rows = n_rows; P.n_nnz = n_nnz; P.status = status; P.fill = 0;
-  hipLaunchKernelGGL(cone_pack_kernel, dim3((unsigned)B), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, P);
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch cone_pack_kernel(count)", e);
+  CAVE_LAUNCH(cone_pack_kernel, waves, B, lds_bytes, stream, P, "cone_pack_kernel(count)");
   return CAVE_OK;
 }
 
 int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t d, int32_t nnz_cap, int32_t lds_bytes,
-                           const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream) {
+                           int32_t waves, const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream) {
   if (B < 0 || m_max < 0 || d <= 0 || d > 65535 || m_max * d >= (int64_t)1 << 32)
     return fail(CAVE_E_INVALID, "pack_fill: bad shape");
   if (B == 0) return CAVE_OK;
   if (!ctrs || !store) return fail(CAVE_E_INVALID, "pack_fill: null pointer");
   if (store->d != d || slot0 < 0 || slot0 + B > store->n) return fail(CAVE_E_INVALID, "pack_fill: store mismatch");
   if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "pack_fill: bad limits");
-  hipError_t e = ensure_lds(cone_pack_kernel, (uint32_t)lds_bytes);
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(cone_pack_kernel)", e);
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_fill: waves must be 0, 1 or 4");
   PackParams P;
   memset(&P, 0, sizeof(P));
   P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
   P.status = status; P.store = *store; P.slot0 = slot0; P.fill = 1;
-  hipLaunchKernelGGL(cone_pack_kernel, dim3((unsigned)B), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, P);
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch cone_pack_kernel(fill)", e);
+  CAVE_LAUNCH(cone_pack_kernel, waves, B, lds_bytes, stream, P, "cone_pack_kernel(fill)");
   return CAVE_OK;
 }
 
@@ -185,22 +209,19 @@ int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz) 
 
 int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
                              int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
-                             float* proj, float* rnorm, float* target, float* loss, float* grad, int32_t* status,
-                             int32_t* iters, void* stream) {
+                             int32_t waves, float* proj, float* rnorm, float* target, float* loss, float* grad,
+                             int32_t* status, int32_t* iters, void* stream) {
   if (!store || B < 0) return fail(CAVE_E_INVALID, "cone_packed: null store / bad B");
   if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed: bad mode");
   if (B == 0) return CAVE_OK;
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed: pred is null");
   if (lds_bytes <= 0 || (uint32_t)lds_bytes > kMaxLds) return fail(CAVE_E_INVALID, "cone_packed: bad lds_bytes");
-  hipError_t e = ensure_lds(cone_packed_kernel, (uint32_t)lds_bytes);
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(cone_packed_kernel)", e);
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_packed: waves must be 0, 1 or 4");
   PackedParams P;
   P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
   P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
-  hipLaunchKernelGGL(cone_packed_kernel, dim3((unsigned)B), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, P);
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch cone_packed_kernel", e);
+  CAVE_LAUNCH(cone_packed_kernel, waves, B, lds_bytes, stream, P, "cone_packed_kernel");
   return CAVE_OK;
 }
 

@@ -81,10 +81,10 @@ CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, i
   cb.d = d;
   cb.m = m;
   cb.ecol = ar.get<uint16_t>(cap);
-  cb.eval = ar.get<float>(cap + 64u);  // +64: per-lane dump slots of the branch-free scan
+  cb.eval = ar.get<float>(cap + (uint32_t)C::NT);  // + per-thread dump slots of the branch-free scan
   cb.rptr = ar.get_top<uint32_t>((uint32_t)m + 1u);
   const uint32_t top_mark = ar.top;
-  uint32_t* eflat = ar.get_top<uint32_t>(cap + 64u);  // flat indices of the non-zeros; dead after finish_scan
+  uint32_t* eflat = ar.get_top<uint32_t>(cap + (uint32_t)C::NT);  // flat indices of the non-zeros; dead after finish_scan
   if (ar.ovf) return ST_TOO_LARGE;
   for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
   c.sync();
@@ -171,7 +171,7 @@ template <class C>
 CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P, int64_t b) {
   const int d = P.d, m = P.m;
   Arena ar;
-  ar.init(smem, P.lds_bytes);
+  ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
   ConeBuild cb;
   CAVE_T0();
   int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
@@ -208,7 +208,7 @@ CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, i
   const int d = P.d, m = P.m;
   const int NT = C::NT;
   Arena ar;
-  ar.init(smem, P.lds_bytes);
+  ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
   ConeBuild cb;
   int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
   if (!P.fill) {
@@ -265,7 +265,7 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
   const int d = S.d;
   const int NT = C::NT;
   Arena ar;
-  ar.init(smem, P.lds_bytes);
+  ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
   const int64_t slot = P.ids ? P.ids[b] : b;
   int32_t st = ST_OK;
   int iters = 0;
@@ -331,10 +331,10 @@ static constexpr uint32_t kMaxLds = 160u * 1024u;
 // `p` reduced rows and `nnzM` reduced non-zeros (the kernel reports ST_TOO_LARGE otherwise).
 static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int64_t rows_raw, int64_t p, int64_t nnzM) {
   // bottom: persistent through the solve
-  uint64_t persist = align8u(2 * cap) + align8u(4 * cap + 256) + align8u(d) + align8u(4 * (d + 1))   // ecol, eval, usign, cptr
+  uint64_t persist = align8u(2 * cap) + align8u(4 * cap + 1024) + align8u(d) + align8u(4 * (d + 1))   // ecol, eval, usign, cptr
                      + 2 * align8u(4 * p) + align8u(p) + align8u(2 * nnzM) + align8u(4 * nnzM);  // mlo, mhi, vkind, CSC
   // top: build-phase temporaries
-  uint64_t scan_temps = align8u(4 * (m + 1)) + align8u(4 * cap + 256);                // rptr, eflat (scan only)
+  uint64_t scan_temps = align8u(4 * (m + 1)) + align8u(4 * cap + 1024);               // rptr, eflat (scan only)
   uint64_t temps = align8u(4 * (m + 1)) + align8u(4 * d) + align8u(m)                 // rptr, ucnt, rowtag
                    + 3 * align8u(4 * rows_raw) + align8u(rows_raw)                     // vraw, vnorm, twin, keep
                    + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // hashes | fill
@@ -344,7 +344,7 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
   if (scan_temps > temps) temps = scan_temps;
   uint64_t build_peak = persist + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
-  return (build_peak > solve_peak ? build_peak : solve_peak) + 64;
+  return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
 }
 
 static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes) {
@@ -382,7 +382,7 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC
   s += align8u(8 * d) * 3 + align8u(d);                                                  // res, tvec, rc, dflag
   int64_t p = max_rows;
-  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128;
+  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
   if (s > kMaxLds) return -1;
   return (int32_t)s;
 }

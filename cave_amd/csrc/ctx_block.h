@@ -1,0 +1,208 @@
+// ctx_block.h — SPMD context: NW cooperating 64-lane waves per instance (workgroup = NW waves).
+//
+// Why: at the benchmark size (B = 1024 on 256 CUs) there is one instance per SIMD, and a lone wave
+// is latency/issue-bound.  Giving each instance a 4-wave workgroup spreads its streaming scan, cone
+// build and every vector phase of the Newton iteration over the CU's four SIMDs (waves of one
+// workgroup are dealt to different SIMDs), while the register-resident Gauss-Jordan solve stays on
+// wave 0.  LDS per instance is unchanged, so residency stays at 4 workgroups per CU.
+//
+// Cross-wave reductions: DPP inside each wave, one LDS slot per wave, ONE barrier (ping-pong
+// buffers make the second barrier unnecessary), fixed summation order -> deterministic.
+// Every method must be called by all threads of the workgroup from uniform control flow.
+#pragma once
+#include "wave_prims.h"
+
+namespace cave {
+
+template <int NW>
+struct BlockCtx {
+  static constexpr int NT = 64 * NW;
+  static constexpr int TEAM = 4;
+  static constexpr int SCAN_UNROLL = 4;  // 4 x 1 KiB per wave per batch, two batches in flight
+  static constexpr int PMAX = 32;        // register budget at 4 waves/SIMD: 128 VGPRs
+  struct Scratch {
+    double f64[2][8];
+    uint32_t u32[2][8];
+  };
+  static constexpr uint32_t SCRATCH_BYTES = 256;
+  static_assert(sizeof(Scratch) <= SCRATCH_BYTES && NW <= 8, "scratch layout");
+  int lane, wave, t;
+  uint32_t par;
+  Scratch* sc;
+#ifdef CAVE_STAMPS
+  unsigned long long st[16];
+#endif
+  __device__ __forceinline__ void init(unsigned char* smem) {
+    t = (int)threadIdx.x;
+    lane = t & 63;
+    wave = t >> 6;
+    par = 0;
+    sc = reinterpret_cast<Scratch*>(smem);
+  }
+  __device__ __forceinline__ int tid() const { return t; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+
+  __device__ __forceinline__ double reduce_sum(double v) {
+    double w = wave_sum_f64(v);
+    if (lane == 0) sc->f64[par][wave] = w;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += sc->f64[par][i];
+    par ^= 1u;
+    return s;
+  }
+  __device__ __forceinline__ double reduce_max(double v) {
+    double w = wave_max_f64(v);
+    if (lane == 0) sc->f64[par][wave] = w;
+    __syncthreads();
+    double s = sc->f64[par][0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) s = fmax(s, sc->f64[par][i]);
+    par ^= 1u;
+    return s;
+  }
+  __device__ __forceinline__ uint32_t reduce_add_u32(uint32_t v) {
+    uint32_t w = wave_sum_u32(v);
+    if (lane == 0) sc->u32[par][wave] = w;
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += sc->u32[par][i];
+    par ^= 1u;
+    return s;
+  }
+  __device__ __forceinline__ double team_reduce_sum(double v) const { return quad_sum_f64(v); }
+  __device__ __forceinline__ void atomic_add_u32(uint32_t* p, uint32_t v) const { atomicAdd(p, v); }
+  __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }
+
+  // publish this wave's count, return (sum over lower waves, total)
+  __device__ __forceinline__ void wave_prefix(uint32_t wcount, uint32_t& pre, uint32_t& tot) {
+    if (lane == 0) sc->u32[par][wave] = wcount;
+    __syncthreads();
+    pre = 0;
+    tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      uint32_t x = sc->u32[par][i];
+      if (i < wave) pre += x;
+      tot += x;
+    }
+    par ^= 1u;
+  }
+
+  __device__ __forceinline__ uint32_t exclusive_scan_u32(uint32_t* a, int n) {
+    uint32_t carry = 0;
+    for (int base = 0; base < n; base += NT) {
+      int i = base + t;
+      uint32_t v = (i < n) ? a[i] : 0u;
+      uint32_t inc = wave_inclusive_scan_u32(v);
+      uint32_t pre, tot;
+      wave_prefix((uint32_t)__builtin_amdgcn_readlane((int)inc, 63), pre, tot);
+      if (i < n) a[i] = carry + pre + inc - v;
+      carry += tot;
+    }
+    __syncthreads();
+    return carry;
+  }
+  __device__ __forceinline__ uint32_t compact_mask_u8(const uint8_t* flags, int n, uint8_t mask, uint8_t val,
+                                                      uint32_t* out, bool negate = false) {
+    uint32_t cnt = 0;
+    for (int base = 0; base < n; base += NT) {
+      int i = base + t;
+      bool pr = (i < n) && (((flags[i] & mask) == val) != negate);
+      uint64_t b = __ballot(pr);
+      uint32_t pre, tot;
+      wave_prefix((uint32_t)__popcll(b), pre, tot);
+      if (pr) out[cnt + pre + mbcnt64(b)] = (uint32_t)i;
+      cnt += tot;
+    }
+    return cnt;
+  }
+  __device__ __forceinline__ uint32_t compact_nonzero_u8(const uint8_t* flags, int n, uint32_t* out) {
+    return compact_mask_u8(flags, n, 0xff, 0, out, true);
+  }
+
+  // wave 0 solves in registers; the caller's sync() publishes dv to the other waves
+  __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
+                                            double reg_rel, double* dv) const {
+    if (wave == 0) gj_solve<32>(lane, H, ldh, g, act, p, reg_rel, dv);
+  }
+
+  // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns
+  // the U consecutive 1 KiB chunks [w*U, (w+1)*U) of a NW*U KiB window, so flat order is
+  // wave-major; one barrier per round turns the per-wave non-zero counts into slot bases.
+  __device__ __forceinline__ uint32_t scan_dense(const float* __restrict__ A, uint32_t n, uint32_t* eflat, float* eval,
+                                                 uint32_t cap) {
+    constexpr int U = SCAN_UNROLL;
+    uint32_t cursor = 0;
+    const uint32_t dump = cap + (uint32_t)t;
+    uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)A & 15u)) & 15u) >> 2);
+    if (head > n) head = n;
+    if (head) scan_single(A, 0u, head, cursor, eflat, eval, cap);
+    const float4* __restrict__ A4 = reinterpret_cast<const float4*>(A + head);
+    const uint32_t n4 = (n - head) >> 2;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t round = 64u * U * NW;
+    const uint32_t woff = (uint32_t)wave * 64u * U + (uint32_t)lane;
+    float4 bufA[U], bufB[U];
+    auto load_batch = [&](float4* buf, uint32_t r0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t i = r0 + woff + (uint32_t)u * 64u;
+        buf[u] = A4[i < n4 ? i : n4 - 1u];  // unconditional dwordx4 from a clamped index
+      }
+    };
+    auto scan_batch = [&](const float4* buf, uint32_t r0) {
+      uint32_t rel[U], nzm = 0, wsum = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t i = r0 + woff + (uint32_t)u * 64u;
+        float4 v = buf[u];
+        if (i >= n4) v = z4;
+        ChunkSlots s = chunk_slots(v);
+        rel[u] = wsum + s.rel;
+        nzm |= s.nzm << (4 * u);
+        wsum += s.total;
+      }
+      uint32_t pre, tot;
+      wave_prefix(wsum, pre, tot);
+      if (tot != 0u) {  // workgroup-uniform
+        const uint32_t base = cursor + pre;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          uint32_t i = r0 + woff + (uint32_t)u * 64u;
+          chunk_emit(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, dump, eflat, eval, cap);
+        }
+      }
+      cursor += tot;
+    };
+    if (n4 > 0) load_batch(bufA, 0);
+    for (uint32_t r0 = 0; r0 < n4; r0 += 2u * round) {
+      if (r0 + round < n4) load_batch(bufB, r0 + round);
+      scan_batch(bufA, r0);
+      if (r0 + round < n4) {
+        if (r0 + 2u * round < n4) load_batch(bufA, r0 + 2u * round);
+        scan_batch(bufB, r0 + round);
+      }
+    }
+    const uint32_t done = head + 4u * n4;
+    if (done < n) scan_single(A, done, n, cursor, eflat, eval, cap);
+    return cursor;
+  }
+  // fewer than 64 stray elements [lo, hi): wave 0, one per lane
+  __device__ __forceinline__ void scan_single(const float* __restrict__ A, uint32_t lo, uint32_t hi, uint32_t& cursor,
+                                              uint32_t* eflat, float* eval, uint32_t cap) {
+    bool valid = (wave == 0) && (lo + (uint32_t)lane < hi);
+    float v = valid ? A[lo + lane] : 0.0f;
+    bool nz = valid && (v != 0.0f);
+    uint64_t m = __ballot(nz);
+    uint32_t pre, tot;
+    wave_prefix((uint32_t)__popcll(m), pre, tot);
+    uint32_t pos = cursor + pre + mbcnt64(m);
+    if (nz && pos < cap) { eflat[pos] = lo + (uint32_t)lane; eval[pos] = v; }
+    cursor += tot;
+  }
+};
+
+}  // namespace cave

@@ -1,0 +1,172 @@
+// wave_prims.h — wave64 primitives for gfx950 used by both SPMD contexts
+// (ctx_wave.h: one wave per instance; ctx_block.h: NW cooperating waves per instance).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "cone_common.h"
+
+namespace cave {
+
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// ---- reductions / scans on the DPP crossbar (no LDS traffic, fixed summation tree)
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_f64(double old, double x) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, RM, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, RM, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, RM, 0xf, false);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xb1, 0xf>(0.0, v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4e, 0xf>(0.0, v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x114, 0xf>(0.0, v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(0.0, v);  // row_shr:8
+  v += dpp_f64<0x142, 0xa>(0.0, v);  // row_bcast:15 -> rows 1,3
+  v += dpp_f64<0x143, 0xc>(0.0, v);  // row_bcast:31 -> rows 2,3
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ double quad_sum_f64(double v) {  // every lane of the quad gets the sum
+  v += dpp_f64<0xb1, 0xf>(0.0, v);
+  v += dpp_f64<0x4e, 0xf>(0.0, v);
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  v = fmax(v, dpp_f64<0xb1, 0xf>(v, v));
+  v = fmax(v, dpp_f64<0x4e, 0xf>(v, v));
+  v = fmax(v, dpp_f64<0x114, 0xf>(v, v));
+  v = fmax(v, dpp_f64<0x118, 0xf>(v, v));
+  v = fmax(v, dpp_f64<0x142, 0xa>(v, v));
+  v = fmax(v, dpp_f64<0x143, 0xc>(v, v));
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  v += dpp_u32<0xb1, 0xf>(0u, v);
+  v += dpp_u32<0x4e, 0xf>(0u, v);
+  v += dpp_u32<0x114, 0xf>(0u, v);
+  v += dpp_u32<0x118, 0xf>(0u, v);
+  v += dpp_u32<0x142, 0xa>(0u, v);
+  v += dpp_u32<0x143, 0xc>(0u, v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// inclusive prefix sum across the 64 lanes (Hillis-Steele inside each 16-lane row, then row carries)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t inc) {
+  inc += dpp_u32<0x111, 0xf>(0u, inc);  // row_shr:1
+  inc += dpp_u32<0x112, 0xf>(0u, inc);  // row_shr:2
+  inc += dpp_u32<0x114, 0xf>(0u, inc);  // row_shr:4
+  inc += dpp_u32<0x118, 0xf>(0u, inc);  // row_shr:8
+  inc += dpp_u32<0x142, 0xa>(0u, inc);  // row_bcast:15 -> rows 1,3
+  inc += dpp_u32<0x143, 0xc>(0u, inc);  // row_bcast:31 -> rows 2,3
+  return inc;
+}
+
+// Solve the p x p system whose free rows are rows of (H + delta*I) and whose
+// fixed rows (act) are identity rows:   H_FF x_F + H_FA x_A = rhs_F,  x_A = rhs_A.
+// ONE wave: lane i keeps row i of [H | rhs] in registers; Gauss-Jordan elimination,
+// pivot row broadcast with v_readlane (no LDS traffic, no barriers).
+template <int PM>
+__device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh, const double* rhs,
+                                              const uint8_t* act, int p, double reg_rel, double* dv) {
+  const bool live = lane < p;
+  const bool my_act = live && act[lane] != 0;
+  double diag0 = (live && !my_act) ? H[lane * ldh + lane] : 0.0;
+  const double maxdiag = wave_max_f64(diag0);
+  const double reg = reg_rel * maxdiag;
+  double h[PM];
+#pragma unroll
+  for (int j = 0; j < PM; ++j) {
+    double v = 0.0;
+    if (j < p) {
+      if (live && !my_act) v = H[lane * ldh + j];
+      if (j == lane) v = my_act ? 1.0 : v + reg;
+    }
+    h[j] = v;
+  }
+  double b = live ? rhs[lane] : 0.0;
+  double diag = 1.0;
+  bool dead = !live;
+  const double thresh = 1e-300;
+#pragma unroll
+  for (int k = 0; k < PM; ++k) {
+    if (k < p) {
+      double piv = readlane_f64(h[k], k);
+      double bk = readlane_f64(b, k);
+      if (piv > thresh) {  // uniform
+        if (lane == k) diag = piv;
+        double fac = (lane == k) ? 0.0 : h[k] / piv;
+#pragma unroll
+        for (int j = k + 1; j < PM; ++j) h[j] -= fac * readlane_f64(h[j], k);  // columns >= p hold zeros
+        b -= fac * bk;
+      } else if (lane == k) {
+        dead = true;
+      }
+    }
+  }
+  if (live) dv[lane] = dead ? 0.0 : b / diag;
+}
+
+// size-specialised dispatch; PLIM bounds the register footprint (2*PM VGPRs for the row)
+template <int PLIM>
+__device__ __forceinline__ void gj_solve(int lane, const double* H, int ldh, const double* g, const uint8_t* act, int p,
+                                         double reg_rel, double* dv) {
+  if (p <= 8) gj_solve_regs<8>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 16) gj_solve_regs<16>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 20) gj_solve_regs<20>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 24) gj_solve_regs<24>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 28) gj_solve_regs<28>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 32) gj_solve_regs<32>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if constexpr (PLIM > 32) {
+    if (p <= 40) gj_solve_regs<40>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 48) gj_solve_regs<48>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 56) gj_solve_regs<56>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else gj_solve_regs<64>(lane, H, ldh, g, act, p, reg_rel, dv);
+  }
+}
+
+// ---- streaming scan building blocks (see scan_dense_* in the contexts)
+// Per 1 KiB chunk (one float4 per lane): which components are non-zero, this lane's ordered slot
+// offset inside the chunk, and the chunk's total.  Lane-major, then component order == flat order.
+struct ChunkSlots {
+  uint32_t rel;    // slot of this lane's first non-zero, relative to the chunk start
+  uint32_t nzm;    // 4-bit component mask
+  uint32_t total;  // wave-uniform
+};
+__device__ __forceinline__ ChunkSlots chunk_slots(float4 v) {
+  bool n0 = v.x != 0.0f, n1 = v.y != 0.0f, n2 = v.z != 0.0f, n3 = v.w != 0.0f;
+  uint64_t m0 = __ballot(n0), m1 = __ballot(n1), m2 = __ballot(n2), m3 = __ballot(n3);
+  ChunkSlots s;
+  s.rel = mbcnt64(m0) + mbcnt64(m1) + mbcnt64(m2) + mbcnt64(m3);
+  s.nzm = (uint32_t)n0 | ((uint32_t)n1 << 1) | ((uint32_t)n2 << 2) | ((uint32_t)n3 << 3);
+  s.total = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+  return s;
+}
+// Branch-free store of a chunk's non-zeros at slots base+rel...; zero components (and slots beyond
+// `cap`) go to this thread's private dump slot (a shared one would serialise on one LDS bank).
+__device__ __forceinline__ void chunk_emit(float4 v, uint32_t f, uint32_t base, uint32_t rel, uint32_t nzm,
+                                           uint32_t dump, uint32_t* eflat, float* eval, uint32_t cap) {
+  const uint32_t p0 = base + rel;
+  const uint32_t p1 = p0 + (nzm & 1u), p2 = p1 + ((nzm >> 1) & 1u), p3 = p2 + ((nzm >> 2) & 1u);
+  const uint32_t i0 = ((nzm & 1u) && p0 < cap) ? p0 : dump, i1 = ((nzm & 2u) && p1 < cap) ? p1 : dump;
+  const uint32_t i2 = ((nzm & 4u) && p2 < cap) ? p2 : dump, i3 = ((nzm & 8u) && p3 < cap) ? p3 : dump;
+  eflat[i0] = f;      eval[i0] = v.x;
+  eflat[i1] = f + 1u; eval[i1] = v.y;
+  eflat[i2] = f + 2u; eval[i2] = v.z;
+  eflat[i3] = f + 3u; eval[i3] = v.w;
+}
+
+}  // namespace cave

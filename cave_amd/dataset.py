@@ -66,7 +66,7 @@ class ConeStore:
             n_rows = torch.empty(B, dtype=torch.int32, device=dev)
             n_nnz = torch.empty(B, dtype=torch.int32, device=dev)
             status = torch.empty(B, dtype=torch.int32, device=dev)
-            _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, 0, 0, _lib.ptr(n_rows), _lib.ptr(n_nnz),
+            _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, 0, 0, 0, _lib.ptr(n_rows), _lib.ptr(n_nnz),
                                                _lib.ptr(status), stream), "cave_hip_pack_count")
             _raise_for_status(status, "ConeStore pack")
             counts.append((n_rows, n_nnz))
@@ -100,10 +100,11 @@ class ConeStore:
             x = ch.to(device=dev, dtype=torch.float32).contiguous()
             B, m, _ = x.shape
             status = torch.empty(B, dtype=torch.int32, device=dev)
-            _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, 0, 0, C.byref(self._c), slot, _lib.ptr(status),
+            _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, 0, 0, 0, C.byref(self._c), slot, _lib.ptr(status),
                                               stream), "cave_hip_pack_fill")
             _raise_for_status(status, "ConeStore fill")
             slot += B
+        self.waves = 4 if self.max_rows <= 32 else 1  # 4-wave workgroups hold reduced systems up to 32 rows
         self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz))
         if self.lds_bytes <= 0:
             raise RuntimeError("ConeStore: largest instance does not fit a 160 KiB LDS arena")
@@ -141,7 +142,7 @@ class ConeStore:
                 return out
             rc = lib.cave_hip_cone_packed(
                 C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                int(max_iter), self.lds_bytes,
+                int(max_iter), self.lds_bytes, self.waves,
                 _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                 _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                 _lib.current_stream())

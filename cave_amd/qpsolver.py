@@ -60,13 +60,16 @@ def _raise_for_status(status: torch.Tensor, what: str) -> None:
 
 def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode: int, sign: float = 1.0,
                   inner_ratio: float = 0.2, *, max_iter: int = 0, nnz_cap: int = 0, lds_bytes: int = 0,
-                  check: bool = True, outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
+                  waves: int = 0, check: bool = True, outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
     """Run the fused per-instance kernel on the reference's dense wire format.
 
     tight_ctrs (B, m_max, d) float32 zero-padded (src/dataset.py:143); pred_cost (B, d).
     ``outputs`` selects which of proj / rnorm / target / loss / grad are materialised.
+    ``waves``: wavefronts per instance (0/4: 4-wave workgroups, reduced systems <= 32 rows;
+    1: one wave per instance, <= 64 rows).
     With ``check=True`` (default) the per-instance status is read back (one host sync):
-    an LDS overflow is retried once with the largest arena, anything else raises.
+    a cone that does not fit is retried once with one wave per instance and the largest
+    arena, anything else raises.
     """
     lib = _lib.load()
     if tight_ctrs.dim() != 3:
@@ -93,33 +96,33 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
         if B == 0:
             return out
 
-        def launch(cap: int, lds: int) -> None:
+        def launch(cap: int, lds: int, nw: int) -> None:
             rc = lib.cave_hip_cone_dense(
                 _lib.ptr(ctrs), _lib.ptr(pred), B, m, d, int(mode), float(sign), float(inner_ratio),
-                int(max_iter), int(cap), int(lds),
+                int(max_iter), int(cap), int(lds), int(nw),
                 _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                 _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                 _lib.current_stream())
             _lib.check(rc, "cave_hip_cone_dense")
 
-        launch(nnz_cap, lds_bytes)
+        launch(nnz_cap, lds_bytes, waves)
         if check:
             if bool((status == ST_TOO_LARGE).any()) and lds_bytes == 0:
                 cap, lds = _grow_limits(m, d)
-                launch(max(cap, nnz_cap), lds)
+                launch(max(cap, nnz_cap), lds, 1)
             _raise_for_status(status, "solver='hip'")
     return out
 
 
 def project_hip(tight_ctrs: torch.Tensor, signed_cost: torch.Tensor, max_iter: int = 0, nnz_cap: int = 0,
-                lds_bytes: int = 0, check: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+                lds_bytes: int = 0, waves: int = 0, check: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
     """(proj, rnorm) on signed_cost's device and dtype — `_batch_project(..., 'nnls')` (src/cave.py:231-264).
 
     ``max_iter`` caps the Newton iterations of the GPU solver (0 = default 100); unlike
     Clarabel's ``max_iter`` it does not produce an interior iterate (src/cave.py:302).
     """
     o = cone_op_dense(tight_ctrs, signed_cost, MODE_PROJECT, 1.0, 0.0, max_iter=max_iter, nnz_cap=nnz_cap,
-                      lds_bytes=lds_bytes, check=check, outputs=("proj", "rnorm"))
+                      lds_bytes=lds_bytes, waves=waves, check=check, outputs=("proj", "rnorm"))
     device, dtype = signed_cost.device, signed_cost.dtype
     return o["proj"].to(device=device, dtype=dtype), o["rnorm"].to(device=device, dtype=dtype)
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 1
+#define CAVE_HIP_ABI_VERSION 2
 
 /* return codes */
 #define CAVE_OK 0
@@ -63,7 +63,9 @@ int32_t cave_hip_device_count(void);
 /* Launch limits.  nnz_cap: per-instance capacity for non-zero entries of the
  * dense block; lds_bytes: dynamic LDS per workgroup (<= 160 KiB).  Pass 0 for
  * either to let the library choose (cave_hip_default_limits reports the
- * choice so a caller can grow it after CAVE_ST_TOO_LARGE). */
+ * choice so a caller can grow it after CAVE_ST_TOO_LARGE).
+ * waves: wavefronts per instance.  4 (default when 0 is passed): a 4-wave workgroup
+ * per instance, reduced systems up to 32 rows; 1: one wave per instance, up to 64 rows. */
 int32_t cave_hip_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes);
 
 /* Fused per-instance operator on the reference's dense wire format.
@@ -83,7 +85,7 @@ int32_t cave_hip_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int3
  */
 int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d,
                             int32_t mode, float sign, float inner_ratio, int32_t max_iter,
-                            int32_t nnz_cap, int32_t lds_bytes,
+                            int32_t nnz_cap, int32_t lds_bytes, int32_t waves,
                             float* proj, float* rnorm, float* target, float* loss, float* grad,
                             int32_t* status, int32_t* iters, void* stream);
 
@@ -92,7 +94,7 @@ int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int
 /* Pass 1: per instance, count reduced rows and their non-zeros.
  *   n_rows [B], n_nnz [B], status [B] */
 int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t d,
-                            int32_t nnz_cap, int32_t lds_bytes,
+                            int32_t nnz_cap, int32_t lds_bytes, int32_t waves,
                             int32_t* n_rows, int32_t* n_nnz, int32_t* status, void* stream);
 
 /* Packed store: structure-of-arrays, all device pointers, filled by cave_hip_pack_fill.
@@ -127,14 +129,14 @@ typedef struct cave_cone_store {
 
 /* Pass 2: fill the store for instances [0, B) of `ctrs` at store slots [slot0, slot0+B). */
 int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t d,
-                           int32_t nnz_cap, int32_t lds_bytes,
+                           int32_t nnz_cap, int32_t lds_bytes, int32_t waves,
                            const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream);
 
 /* Same operator as cave_hip_cone_dense, reading cones from the store:
  *   ids [B] int64 store slots (the collate_fn replacement hands these out). */
 int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
                              int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
-                             float* proj, float* rnorm, float* target, float* loss, float* grad,
+                             int32_t waves, float* proj, float* rnorm, float* target, float* loss, float* grad,
                              int32_t* status, int32_t* iters, void* stream);
 
 /* LDS bytes cave_hip_cone_packed needs for the largest instance of a store

@@ -12,6 +12,7 @@ namespace cave {
 struct SerialCtx {
   static constexpr int NT = 1;
   static constexpr int TEAM = 1;
+  static constexpr uint32_t SCRATCH_BYTES = 0;
   double team_reduce_sum(double v) const { return v; }
   static constexpr int PMAX = 64;
   int tid() const { return 0; }

@@ -20,7 +20,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cave_hip_version() == 1
+    assert lib.cave_hip_version() == 2
     assert lib.cave_hip_device_count() >= 0
     assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
 
@@ -32,11 +32,11 @@ def test_default_limits_and_arg_validation():
     assert cap == 150 and lds <= 16 * 1024
     lib = _lib.load_library()
     # bad shapes are rejected before any launch (works without a GPU)
-    assert lib.cave_hip_cone_dense(None, None, 1, 4, 0, 0, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.cave_hip_cone_dense(None, None, 1, 4, 0, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
     assert b"bad shape" in lib.cave_hip_last_error()
-    assert lib.cave_hip_cone_dense(None, None, 1, 4, 70000, 0, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
-    assert lib.cave_hip_cone_dense(None, None, 1, 4, 4, 9, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
-    assert lib.cave_hip_cone_dense(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 0, 0, None, None, None, None, None, None, None, None) == 0  # B == 0
+    assert lib.cave_hip_cone_dense(None, None, 1, 4, 70000, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.cave_hip_cone_dense(None, None, 1, 4, 4, 9, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.cave_hip_cone_dense(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == 0  # B == 0
     assert lib.cave_hip_packed_lds_bytes(190, 26, 700) > 0
     assert lib.cave_hip_packed_lds_bytes(190, 5000, 700) == -1
 

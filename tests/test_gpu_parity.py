@@ -27,9 +27,11 @@ def hip():
     return impl
 
 
+@pytest.mark.parametrize("waves", [4, 1])
 @pytest.mark.parametrize("file,tag", CASES)
-def test_hip_matches_reference_outputs(hip, golden, file, tag):
-    check_case(hip, golden, file, tag)
+def test_hip_matches_reference_outputs(hip, golden, file, tag, waves):
+    """Both workgroup shapes: 4 cooperating waves per instance (default) and one wave per instance."""
+    check_case(lambda *a: hip(*a, waves=waves), golden, file, tag)
 
 
 def test_hip_random_cones_vs_oracle(hip):
@@ -45,7 +47,7 @@ def test_hip_random_cones_vs_oracle(hip):
             A[:, m // 2:] = 0
             A[:, 1] = -A[:, 0]
         y = rng.standard_normal((B, d)).astype(np.float32)
-        o = hip(A, y, MODE_PROJECT, 1.0, 0.0)
+        o = hip(A, y, MODE_PROJECT, 1.0, 0.0, waves=(4 if trial % 2 else 1))
         po, ro = O.batch_project(y, A)
         sc = np.maximum(1.0, np.abs(y).max(axis=1))[:, None]
         assert np.all(np.abs(o["proj"] - po) <= 4e-6 * sc)
