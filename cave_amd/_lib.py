@@ -53,7 +53,7 @@ class Store(C.Structure):
     """struct cave_cone_store (include/cave_hip.h)."""
     _fields_ = [
         ("n", C.c_int64), ("d", C.c_int32), ("reserved", C.c_int32),
-        ("row_off", C.c_void_p), ("nnz_off", C.c_void_p), ("n_valid", C.c_void_p),
+        ("row_off", C.c_void_p), ("nnz_off", C.c_void_p), ("n_valid", C.c_void_p), ("flags", C.c_void_p),
         ("usign", C.c_void_p), ("avg", C.c_void_p), ("vkind", C.c_void_p),
         ("rlo", C.c_void_p), ("rhi", C.c_void_p), ("ccol", C.c_void_p), ("cval", C.c_void_p),
         ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),

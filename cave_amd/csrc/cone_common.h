@@ -89,14 +89,14 @@ struct SolveView {
   int d;                  // cost dimension
   int p;                  // reduced unknowns: one per general row (a +a/-a pair counts once)
   int n_valid;            // rows kept by the projection (0 -> empty cone -> proj = y)
-  const uint32_t* mlo;    // [p]  CSR row begin of reduced row i in (ecol, eval)
-  const uint32_t* mhi;    // [p]  CSR row end
-  const uint16_t* ecol;
-  const float* eval;
+  bool pm1;               // every reduced-row entry is +-1: sign in bit 15 of mcol / cvar, no value arrays
+  const uint32_t* mptr;   // [p+1] CSR row pointers of the reduced rows
+  const uint16_t* mcol;   // [nnzM]
+  const float* mval;      // [nnzM]  (null when pm1)
   const uint8_t* vkind;   // [p]  1 = free multiplier (paired row), 0 = non-negative
   const uint32_t* cptr;   // [d+1] CSC of the reduced rows
-  const uint16_t* cvar;
-  const float* cvalc;
+  const uint16_t* cvar;   // [nnzM]
+  const float* cvalc;     // [nnzM]  (null when pm1)
   const uint8_t* usign;   // [d]  bit0: +e_k row present, bit1: -e_k row present
   int nlong;              // reduced rows with more than kLongRow entries ...
   const uint32_t* longrow;  // ... and their indices

@@ -26,32 +26,50 @@ namespace cave {
 struct ConeBuild {
   int d, m;
   uint32_t nnz_all;  // non-zeros of the whole instance (row-major order)
-  uint16_t* ecol;    // [nnz_cap]
-  float* eval;       // [nnz_cap]
+  // ---- build-phase temporaries (top of the arena; dropped by Arena::release_top)
+  uint32_t* erc;     // [cap] (row << 16) | col of every non-zero
+  float* eall;       // [cap] its value
   uint32_t* rptr;    // [m+1]
   uint32_t* ucnt;    // [d] low 16 bits: number of +e_k rows, high 16 bits: number of -e_k rows
-  uint8_t* usign;    // [d]
+  float* rs2;        // [m] squared l2 norm of each row
   uint8_t* rowtag;   // [m]
   uint32_t* vraw;    // [p_raw] general rows, in row order (both twins of a pair)
   float* vnorm;      // [p_raw] l2 norm of those rows
   int p_raw;
-  uint32_t* mlo;     // [p]
-  uint32_t* mhi;     // [p]
+  // ---- persistent (bottom of the arena): what the solver reads
+  uint8_t* usign;    // [d]
+  bool pm1;          // every reduced-row entry is +-1: the sign sits in bit 15 of mcol / cvar, no value arrays
+  uint32_t* mptr;    // [p+1] CSR row pointers of the reduced rows
+  uint16_t* mcol;    // [nnzM]
+  float* mval;       // [nnzM]  (null when pm1)
   uint8_t* vkind;    // [p]
   int p;
   uint32_t nnzM;
   uint32_t* cptr;    // [d+1]
   uint16_t* cvar;    // [nnzM]
-  float* cvalc;      // [nnzM]
+  float* cvalc;      // [nnzM]  (null when pm1)
   int n_valid_proj;
   int n_valid_avg;
 };
 
 static constexpr uint32_t kHashPrefix = 12;
+static constexpr uint32_t kLongRow = 64;   // rows longer than this are handled by the whole team, one at a time
+static constexpr uint8_t ROW_PM1 = 0x20;   // every entry of the row is +-1
+static constexpr uint8_t ROW_PENDING = 0xFF;
 
-// Classify rows, detect +a/-a pairs, build CSR/CSC of the reduced rows.
-// Pre: cb.ecol/eval/rptr hold the scan output (rptr = per-row counts, m+1 entries,
-// last = 0), cb.nnz_all set.  Returns ST_OK or ST_TOO_LARGE.
+CAVE_HD uint8_t classify_row(float s1, float s2, bool allpm1, uint32_t len) {
+  uint8_t tag = ROW_DROP;
+  if (s1 > kDropRowAbsSum) {  // src/cave.py:303
+    tag = (len == 1) ? ROW_UNIT : ROW_GENERAL;
+    if (sqrtf(s2) > kAvgRowNorm) tag |= ROW_AVG_VALID;  // src/cave.py:224-225
+    if (allpm1) tag |= ROW_PM1;
+  }
+  return tag;
+}
+
+// Classify rows, detect +a/-a pairs, build compact CSR/CSC of the reduced rows.
+// Pre: cb.erc/eall hold the scan output in row-major order, cb.rptr the per-row counts
+// (m+1 entries, last = 0), cb.nnz_all set.  Returns ST_OK or ST_TOO_LARGE.
 template <class C>
 CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   const int d = cb.d, m = cb.m;
@@ -60,40 +78,63 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   // 1. row counts -> row pointers
   c.exclusive_scan_u32(cb.rptr, m + 1);
   cb.ucnt = ar.get_top<uint32_t>(d);
-  cb.usign = ar.get<uint8_t>(d);
+  cb.rs2 = ar.get_top<float>(m > 0 ? m : 1);
   cb.rowtag = ar.get_top<uint8_t>(m > 0 ? m : 1);
+  const uint32_t nlong_cap = cb.nnz_all / kLongRow + 1u;
+  uint32_t* longrows = ar.get_top<uint32_t>(nlong_cap);
+  cb.usign = ar.get<uint8_t>(d);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int k = c.tid(); k < d; k += NT) cb.ucnt[k] = 0;
   c.sync();
-  // 2. per-row statistics and tags
-  uint32_t nvp = 0, nva = 0, ngen = 0;
+  // 2. per-row statistics and tags (one thread per row; long rows are left pending)
   for (int r = c.tid(); r < m; r += NT) {
-    uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+    const uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+    if (hi - lo > kLongRow) { cb.rowtag[r] = ROW_PENDING; continue; }
     float s1 = 0.f, s2 = 0.f;
+    bool allpm1 = true;
     for (uint32_t e = lo; e < hi; ++e) {
-      float v = cb.eval[e];
+      float v = cb.eall[e];
       s1 += fabsf(v);
       s2 += v * v;
+      allpm1 = allpm1 && (fabsf(v) == 1.0f);
     }
-    uint8_t tag = ROW_DROP;
-    if (s1 > kDropRowAbsSum) {  // src/cave.py:303
-      nvp++;
-      if (hi - lo == 1) {
-        tag = ROW_UNIT;
-        uint16_t col = cb.ecol[lo];
-        c.atomic_add_u32(&cb.ucnt[col], cb.eval[lo] > 0.f ? 1u : 0x10000u);
-      } else {
-        tag = ROW_GENERAL;
-        ngen++;
-      }
-      if (sqrtf(s2) > kAvgRowNorm) { tag |= ROW_AVG_VALID; nva++; }  // src/cave.py:224-225
-    }
+    const uint8_t tag = classify_row(s1, s2, allpm1, hi - lo);
     cb.rowtag[r] = tag;
+    cb.rs2[r] = s2;
+    if ((tag & 0x0F) == ROW_UNIT) c.atomic_add_u32(&cb.ucnt[cb.erc[lo] & 0xffffu], cb.eall[lo] > 0.f ? 1u : 0x10000u);
+  }
+  c.sync();
+  const uint32_t nlong = c.compact_mask_u8(cb.rowtag, m, 0xFF, ROW_PENDING, longrows);
+  c.sync();
+  for (uint32_t li = 0; li < nlong; ++li) {  // whole team per long row, fixed summation tree
+    const uint32_t r = longrows[li];
+    const uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+    double s1 = 0.0, s2 = 0.0, bad = 0.0;
+    for (uint32_t e = lo + c.tid(); e < hi; e += NT) {
+      float v = cb.eall[e];
+      s1 += (double)fabsf(v);
+      s2 += (double)v * (double)v;
+      if (fabsf(v) != 1.0f) bad = 1.0;
+    }
+    s1 = c.reduce_sum(s1);
+    s2 = c.reduce_sum(s2);
+    bad = c.reduce_max(bad);
+    if (c.tid() == 0) {
+      cb.rowtag[r] = classify_row((float)s1, (float)s2, bad == 0.0, hi - lo);
+      cb.rs2[r] = (float)s2;
+    }
+  }
+  c.sync();
+  uint32_t nvp = 0, nva = 0, ngen = 0;
+  for (int r = c.tid(); r < m; r += NT) {
+    const uint8_t tag = cb.rowtag[r];
+    nvp += (tag & 0x0F) != ROW_DROP;
+    nva += (tag & ROW_AVG_VALID) != 0;
+    ngen += (tag & 0x0F) == ROW_GENERAL;
   }
   cb.n_valid_proj = (int)c.reduce_add_u32(nvp);
   cb.n_valid_avg = (int)c.reduce_add_u32(nva);
   cb.p_raw = (int)c.reduce_add_u32(ngen);
-  c.sync();
   for (int k = c.tid(); k < d; k += NT)
     cb.usign[k] = (uint8_t)(((cb.ucnt[k] & 0xffffu) ? 1 : 0) | ((cb.ucnt[k] >> 16) ? 2 : 0));
   CAVE_ACC(11);
@@ -103,12 +144,12 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   cb.vnorm = ar.get_top<float>(pr > 0 ? pr : 1);
   uint32_t* twin = ar.get_top<uint32_t>(pr > 0 ? pr : 1);
   uint8_t* keep = ar.get_top<uint8_t>(pr > 0 ? pr : 1);
+  uint16_t* rowvar = ar.get_top<uint16_t>(m > 0 ? m : 1);
   cb.cptr = ar.get<uint32_t>(d + 1);
   if (ar.ovf) return ST_TOO_LARGE;
   c.compact_mask_u8(cb.rowtag, m, 0x0F, ROW_GENERAL, cb.vraw);
   c.sync();
-  // 4. pair detection by (hash(+a), hash(-a)); hashes live in scratch carved after
-  //    the persistent arrays and released again below.
+  // 4. pair detection by (signature(+a), signature(-a)); signatures live in scratch released below
   const uint32_t top_mark = ar.top;
   uint64_t* hp = ar.get_top<uint64_t>(pr > 0 ? pr : 1);
   uint64_t* hn = ar.get_top<uint64_t>(pr > 0 ? pr : 1);
@@ -119,23 +160,19 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
     // signature of the row and of its negation: length + the first kHashPrefix entries (two 32-bit
     // FNV-1a streams each).  Candidates are verified entry by entry below, so a prefix is enough.
     uint32_t a0 = 0x811c9dc5u ^ (hi - lo), a1 = 0x9747b28cu + (hi - lo), b0 = a0, b1 = a1;
-    float s2 = 0.f;
-    for (uint32_t e = lo; e < hi; ++e) {
-      float val = cb.eval[e];
-      s2 += val * val;
-      if (e - lo < kHashPrefix) {
-        uint32_t u = f2u(val), col = cb.ecol[e];
-        uint32_t xp = u ^ (col * 0x9e3779b1u), xn = (u ^ 0x80000000u) ^ (col * 0x9e3779b1u);
-        // xor-shift after each multiply so the sign bit (bit 31) reaches the low bits
-        a0 = (a0 ^ xp) * 0x01000193u; a0 ^= a0 >> 15;
-        a1 = (a1 + xp) * 0x85ebca6bu; a1 ^= a1 >> 13;
-        b0 = (b0 ^ xn) * 0x01000193u; b0 ^= b0 >> 15;
-        b1 = (b1 + xn) * 0x85ebca6bu; b1 ^= b1 >> 13;
-      }
+    const uint32_t hend = (hi - lo < kHashPrefix) ? hi : lo + kHashPrefix;
+    for (uint32_t e = lo; e < hend; ++e) {
+      uint32_t u = f2u(cb.eall[e]), col = cb.erc[e] & 0xffffu;
+      uint32_t xp = u ^ (col * 0x9e3779b1u), xn = (u ^ 0x80000000u) ^ (col * 0x9e3779b1u);
+      // xor-shift after each multiply so the sign bit (bit 31) reaches the low bits
+      a0 = (a0 ^ xp) * 0x01000193u; a0 ^= a0 >> 15;
+      a1 = (a1 + xp) * 0x85ebca6bu; a1 ^= a1 >> 13;
+      b0 = (b0 ^ xn) * 0x01000193u; b0 ^= b0 >> 15;
+      b1 = (b1 + xn) * 0x85ebca6bu; b1 ^= b1 >> 13;
     }
     hp[i] = ((uint64_t)a1 << 32) | a0;
     hn[i] = ((uint64_t)b1 << 32) | b0;
-    cb.vnorm[i] = sqrtf(s2);
+    cb.vnorm[i] = sqrtf(cb.rs2[r]);
   }
   c.sync();
   for (int i = c.tid(); i < pr; i += NT) {
@@ -155,7 +192,7 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
       uint32_t lo2 = cb.rptr[q], hi2 = cb.rptr[q + 1];
       bool ok = (hi - lo) == (hi2 - lo2);
       for (uint32_t e = 0; ok && e < hi - lo; ++e)
-        ok = (cb.ecol[lo + e] == cb.ecol[lo2 + e]) && (cb.eval[lo + e] == -cb.eval[lo2 + e]);
+        ok = ((cb.erc[lo + e] & 0xffffu) == (cb.erc[lo2 + e] & 0xffffu)) && (cb.eall[lo + e] == -cb.eall[lo2 + e]);
       if (ok) t = cand;
     }
     twin[i] = t;
@@ -168,53 +205,87 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
     keep[i] = (uint8_t)((paired && t < (uint32_t)i) ? 0 : (paired ? 2 : 1));
   }
   c.sync();
-  ar.top = top_mark;  // release hash scratch
+  ar.top = top_mark;  // release signature scratch
   CAVE_ACC(12);
   // 5. reduced variable list (ordered): reuse twin[] as the compacted index list
   uint32_t* vidx = twin;  // overwritten below only after keep[] has been fully derived
   cb.p = (int)c.compact_nonzero_u8(keep, pr, vidx);
   c.sync();
   const int p = cb.p;
-  cb.mlo = ar.get<uint32_t>(p > 0 ? p : 1);
-  cb.mhi = ar.get<uint32_t>(p > 0 ? p : 1);
+  cb.mptr = ar.get<uint32_t>((uint32_t)p + 1u);
   cb.vkind = ar.get<uint8_t>(p > 0 ? p : 1);
   if (ar.ovf) return ST_TOO_LARGE;
-  uint32_t nnzM_local = 0;
-  for (int i = c.tid(); i < p; i += NT) {
-    uint32_t src = vidx[i];
-    uint32_t r = cb.vraw[src];
-    cb.mlo[i] = cb.rptr[r];
-    cb.mhi[i] = cb.rptr[r + 1];
-    cb.vkind[i] = (uint8_t)(keep[src] == 2 ? 1 : 0);
-    nnzM_local += cb.rptr[r + 1] - cb.rptr[r];
-  }
-  cb.nnzM = c.reduce_add_u32(nnzM_local);
+  for (int r = c.tid(); r < m; r += NT) rowvar[r] = 0xffffu;
+  if (c.tid() == 0) cb.mptr[p] = 0u;
   c.sync();
-  // 6. CSC of the reduced rows
-  cb.cvar = ar.get<uint16_t>(cb.nnzM > 0 ? cb.nnzM : 1);
-  cb.cvalc = ar.get<float>(cb.nnzM > 0 ? cb.nnzM : 1);
+  uint32_t notpm1 = 0;
+  for (int i = c.tid(); i < p; i += NT) {
+    const uint32_t src = vidx[i];
+    const uint32_t r = cb.vraw[src];
+    rowvar[r] = (uint16_t)i;
+    cb.mptr[i] = cb.rptr[r + 1] - cb.rptr[r];
+    cb.vkind[i] = (uint8_t)(keep[src] == 2 ? 1 : 0);
+    notpm1 += (cb.rowtag[r] & ROW_PM1) ? 0u : 1u;
+  }
+  notpm1 = c.reduce_add_u32(notpm1);
+  cb.pm1 = (notpm1 == 0u) && d <= 0x7fff && p <= 0x7fff;
+  c.sync();
+  cb.nnzM = c.exclusive_scan_u32(cb.mptr, p + 1);
+  // 6. compact CSR + CSC of the reduced rows
+  const uint32_t nz = cb.nnzM > 0 ? cb.nnzM : 1u;
+  cb.mcol = ar.get<uint16_t>(nz);
+  cb.cvar = ar.get<uint16_t>(nz);
+  cb.mval = cb.pm1 ? nullptr : ar.get<float>(nz);
+  cb.cvalc = cb.pm1 ? nullptr : ar.get<float>(nz);
   const uint32_t top_mark2 = ar.top;
   uint32_t* fill = ar.get_top<uint32_t>(d);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int k = c.tid(); k <= d; k += NT) cb.cptr[k] = 0;
   for (int k = c.tid(); k < d; k += NT) fill[k] = 0;
   c.sync();
-  for (int i = c.tid(); i < p; i += NT)
-    for (uint32_t e = cb.mlo[i]; e < cb.mhi[i]; ++e) c.atomic_add_u32(&cb.cptr[cb.ecol[e]], 1u);
+  const bool pm1 = cb.pm1;
+  for (uint32_t e = c.tid(); e < cb.nnz_all; e += NT) {  // one thread per non-zero of the instance
+    const uint32_t rc = cb.erc[e], r = rc >> 16, col = rc & 0xffffu;
+    const uint32_t var = rowvar[r];
+    if (var == 0xffffu) continue;
+    const float val = cb.eall[e];
+    const uint32_t dst = cb.mptr[var] + (e - cb.rptr[r]);
+    cb.mcol[dst] = (uint16_t)(pm1 ? (col | (val < 0.f ? 0x8000u : 0u)) : col);
+    if (!pm1) cb.mval[dst] = val;
+    c.atomic_add_u32(&cb.cptr[col], 1u);
+  }
   c.sync();
   c.exclusive_scan_u32(cb.cptr, d + 1);
   c.sync();
-  for (int i = 0; i < p; ++i) {  // rows in order -> entries of a column sorted by variable
-    uint32_t lo = cb.mlo[i], hi = cb.mhi[i];
-    for (uint32_t e = lo + c.tid(); e < hi; e += NT) {
-      uint16_t col = cb.ecol[e];
-      uint32_t pos = cb.cptr[col] + fill[col];
-      fill[col] += 1;  // columns within one row are distinct: no conflict
-      cb.cvar[pos] = (uint16_t)i;
-      cb.cvalc[pos] = cb.eval[e];
-    }
-    c.sync();
+  for (uint32_t e = c.tid(); e < cb.nnz_all; e += NT) {
+    const uint32_t rc = cb.erc[e], r = rc >> 16, col = rc & 0xffffu;
+    const uint32_t var = rowvar[r];
+    if (var == 0xffffu) continue;
+    const float val = cb.eall[e];
+    const uint32_t pos = cb.cptr[col] + c.atomic_inc_ret_u32(&fill[col]);
+    cb.cvar[pos] = (uint16_t)(pm1 ? (var | (val < 0.f ? 0x8000u : 0u)) : var);
+    if (!pm1) cb.cvalc[pos] = val;
   }
+  c.sync();
+  // the atomic cursor leaves each column in arbitrary order: insertion-sort it by reduced-row index
+  // (one thread per column; columns are short) so every later summation order is fixed
+  const uint32_t vmask = pm1 ? 0x7fffu : 0xffffu;
+  for (int k = c.tid(); k < d; k += NT) {
+    const uint32_t lo = cb.cptr[k], hi = cb.cptr[k + 1];
+    for (uint32_t a = lo + 1; a < hi; ++a) {
+      const uint16_t kv = cb.cvar[a];
+      const float kf = pm1 ? 0.f : cb.cvalc[a];
+      uint32_t b = a;
+      while (b > lo && (cb.cvar[b - 1] & vmask) > (kv & vmask)) {
+        cb.cvar[b] = cb.cvar[b - 1];
+        if (!pm1) cb.cvalc[b] = cb.cvalc[b - 1];
+        --b;
+      }
+      cb.cvar[b] = kv;
+      if (!pm1) cb.cvalc[b] = kf;
+    }
+  }
+  c.sync();
   ar.top = top_mark2;  // release fill[]
   CAVE_ACC(13);
   return ST_OK;
@@ -230,7 +301,7 @@ CAVE_HD void compute_avg(C& c, const ConeBuild& cb, float* avg) {
     uint32_t r = cb.vraw[i];
     if (!(cb.rowtag[r] & ROW_AVG_VALID)) continue;  // uniform
     float inv = 1.0f / fmaxf(cb.vnorm[i], (float)kNormClamp);
-    for (uint32_t e = cb.rptr[r] + c.tid(); e < cb.rptr[r + 1]; e += NT) avg[cb.ecol[e]] += cb.eval[e] * inv;
+    for (uint32_t e = cb.rptr[r] + c.tid(); e < cb.rptr[r + 1]; e += NT) avg[cb.erc[e] & 0xffffu] += cb.eall[e] * inv;
     c.sync();
   }
   float invn = 1.0f / (float)(cb.n_valid_avg > 1 ? cb.n_valid_avg : 1);
@@ -239,6 +310,21 @@ CAVE_HD void compute_avg(C& c, const ConeBuild& cb, float* avg) {
 }
 
 // --------------------------------------------------------------------- solver
+
+// entry e of the reduced CSR / CSC: index and value (value = sign bit of the index when v.pm1)
+// (PM1 is a compile-time copy of v.pm1 so the hot loops carry no mode test)
+template <bool PM1>
+CAVE_HD void csr_entry(const SolveView& v, uint32_t e, uint32_t& col, double& val) {
+  const uint32_t x = v.mcol[e];
+  if (PM1) { col = x & 0x7fffu; val = (x & 0x8000u) ? -1.0 : 1.0; }
+  else { col = x; val = (double)v.mval[e]; }
+}
+template <bool PM1>
+CAVE_HD void csc_entry(const SolveView& v, uint32_t e, uint32_t& var, double& val) {
+  const uint32_t x = v.cvar[e];
+  if (PM1) { var = x & 0x7fffu; val = (x & 0x8000u) ? -1.0 : 1.0; }
+  else { var = x; val = (double)v.cvalc[e]; }
+}
 
 CAVE_HD double clip_unit(double r, uint8_t u) {
   // residual left after the best multipliers of the +e_k / -e_k rows (closed form)
@@ -249,11 +335,16 @@ CAVE_HD double clip_unit(double r, uint8_t u) {
 }
 
 // out[k] = base[k] - (M^T th)[k]   (base = y, or null for 0);  one CSC gather pass
-template <class C>
+template <class C, bool PM1>
 CAVE_HD void gather_mt(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
   for (int k = c.tid(); k < v.d; k += C::NT) {
     double r = base ? (double)base[k] : 0.0;
-    for (uint32_t e = v.cptr[k]; e < v.cptr[k + 1]; ++e) r += sgn * (double)v.cvalc[e] * th[v.cvar[e]];
+    for (uint32_t e = v.cptr[k]; e < v.cptr[k + 1]; ++e) {
+      uint32_t var;
+      double val;
+      csc_entry<PM1>(v, e, var, val);
+      r += sgn * val * th[var];
+    }
     out[k] = r;
   }
   c.sync();
@@ -275,9 +366,8 @@ CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double
 
 // g = -M rc.  Rows are shared by TEAM adjacent lanes (fixed reduction tree); rows longer than
 // kLongRow entries are summed by the whole team of NT lanes, one row at a time.
-static constexpr uint32_t kLongRow = 64;
 
-template <class C>
+template <class C, bool PM1>
 CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
   constexpr int TEAM = C::TEAM;
   constexpr int RPP = C::NT / TEAM;  // rows per pass
@@ -287,18 +377,28 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
     const bool valid = i < v.p;
     double part = 0.0;
     uint32_t lo = 0, hi = 0;
-    if (valid) { lo = v.mlo[i]; hi = v.mhi[i]; }
+    if (valid) { lo = v.mptr[i]; hi = v.mptr[i + 1]; }
     const bool is_long = (hi - lo) > kLongRow;
     if (valid && !is_long)
-      for (uint32_t e = lo + sub; e < hi; e += TEAM) part -= (double)v.eval[e] * rc[v.ecol[e]];
+      for (uint32_t e = lo + sub; e < hi; e += TEAM) {
+        uint32_t col;
+        double val;
+        csr_entry<PM1>(v, e, col, val);
+        part -= val * rc[col];
+      }
     part = c.team_reduce_sum(part);
     if (valid && !is_long && sub == 0) g[i] = part;
   }
   for (int li = 0; li < v.nlong; ++li) {
     const int i = (int)v.longrow[li];
-    const uint32_t lo = v.mlo[i], hi = v.mhi[i];
+    const uint32_t lo = v.mptr[i], hi = v.mptr[i + 1];
     double part = 0.0;
-    for (uint32_t e = lo + c.tid(); e < hi; e += C::NT) part -= (double)v.eval[e] * rc[v.ecol[e]];
+    for (uint32_t e = lo + c.tid(); e < hi; e += C::NT) {
+      uint32_t col;
+      double val;
+      csr_entry<PM1>(v, e, col, val);
+      part -= val * rc[col];
+    }
     part = c.reduce_sum(part);
     if (c.tid() == 0) g[i] = part;
   }
@@ -329,8 +429,8 @@ CAVE_HD void dphi(C& c, const SolveView& v, const double* r, const double* q, do
 // quadratic (no unit rows) the outer loop is a block active-set NNLS method.
 //
 // On return w.res holds the CLIPPED residual Pi(y - M^T theta).
-template <class C>
-CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
+template <class C, bool PM1>
+CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
   const int NT = C::NT;
   const int p = v.p, d = v.d;
   SolveResult out;
@@ -357,7 +457,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
   CAVE_T0();
   for (; p > 0 && it < max_iter; ++it) {
     // gradient g = -M Pi(r) and projected-gradient norm
-    gradient(c, v, rc, w.g);
+    gradient<C, PM1>(c, v, rc, w.g);
     double pgmax = 0.0;
     for (int i = c.tid(); i < p; i += NT) {
       double gi = w.g[i];
@@ -380,12 +480,14 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
       const double sg = on ? 1.0 : -1.0;
       uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
       for (uint32_t e1 = lo; e1 < hi; ++e1) {
-        uint32_t a = v.cvar[e1];
-        double va = sg * (double)v.cvalc[e1];
-        c.atomic_add_f64(&w.H[a * ldh + a], va * (double)v.cvalc[e1]);
+        uint32_t a, b;
+        double v1, v2;
+        csc_entry<PM1>(v, e1, a, v1);
+        const double va = sg * v1;
+        c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
         for (uint32_t e2 = lo; e2 < e1; ++e2) {
-          uint32_t b = v.cvar[e2];
-          double vv = va * (double)v.cvalc[e2];
+          csc_entry<PM1>(v, e2, b, v2);
+          double vv = va * v2;
           c.atomic_add_f64(&w.H[a * ldh + b], vv);
           c.atomic_add_f64(&w.H[b * ldh + a], vv);
         }
@@ -475,7 +577,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
     if (amax < 1.0) amax = 1.0;
     c.sync();
     if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n); break; }
-    gather_mt(c, v, nullptr, w.dv, 1.0, w.q);  // q = M^T dv, so r(alpha) = r - alpha q
+    gather_mt<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);  // q = M^T dv, so r(alpha) = r - alpha q
     CAVE_ACC(6);
     double alpha = 1.0, lo = 0.0, hi = amax;
     double d1, d2;
@@ -507,7 +609,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
     }
     c.sync();
     CAVE_ACC(7);
-    if ((it & 7) == 7) gather_mt(c, v, w.y, theta, -1.0, r);  // periodic fresh residual bounds the drift
+    if ((it & 7) == 7) gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);  // periodic fresh residual bounds the drift
     else {
       for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
       c.sync();
@@ -530,7 +632,7 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
   }
   // final residual straight from theta (the iteration updated r incrementally), clipped for the epilogue
   if (p > 0) {
-    gather_mt(c, v, w.y, theta, -1.0, r);
+    gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
     f = refresh_clipped(c, v, r, rc);
   }
   for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];
@@ -540,6 +642,11 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
   out.f = f;
   out.iters = it;
   return out;
+}
+
+template <class C>
+CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
+  return v.pm1 ? solve_cone_impl<C, true>(c, v, w, max_iter, tol) : solve_cone_impl<C, false>(c, v, w, max_iter, tol);
 }
 
 // ------------------------------------------------------------------- epilogue

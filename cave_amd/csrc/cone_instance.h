@@ -80,34 +80,42 @@ template <class C>
 CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, int m, int d, uint32_t cap) {
   cb.d = d;
   cb.m = m;
-  cb.ecol = ar.get<uint16_t>(cap);
-  cb.eval = ar.get<float>(cap + (uint32_t)C::NT);  // + per-thread dump slots of the branch-free scan
+  if (m > 0xffff) return ST_TOO_LARGE;  // (row << 16) | col packing of the scan output
+  // scan output = build-phase temporaries at the top of the arena (+ per-thread dump slots)
+  cb.erc = ar.get_top<uint32_t>(cap + (uint32_t)C::NT);
+  cb.eall = ar.get_top<float>(cap + (uint32_t)C::NT);
   cb.rptr = ar.get_top<uint32_t>((uint32_t)m + 1u);
-  const uint32_t top_mark = ar.top;
-  uint32_t* eflat = ar.get_top<uint32_t>(cap + (uint32_t)C::NT);  // flat indices of the non-zeros; dead after finish_scan
   if (ar.ovf) return ST_TOO_LARGE;
   for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
   c.sync();
   CAVE_T0();
-  uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, eflat, cb.eval, cap);
+  uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);  // erc = flat index for now
   c.sync();
   CAVE_ACC(10);
   if (nnz > cap) return ST_TOO_LARGE;
-  // row / column of every entry (f = row*d + col) and the per-row counts
+  // flat index f = row*d + col  ->  (row << 16) | col, and the per-row counts
   const double inv_d = 1.0 / (double)d;
   for (uint32_t e = c.tid(); e < nnz; e += C::NT) {
-    const uint32_t f = eflat[e];
+    const uint32_t f = cb.erc[e];
     uint32_t row = (uint32_t)((double)f * inv_d);  // within +-1 of f / d for f < 2^32
     int32_t col = (int32_t)(f - row * (uint32_t)d);
     if (col < 0) { row -= 1u; col += d; }
     else if (col >= d) { row += 1u; col -= d; }
-    cb.ecol[e] = (uint16_t)col;
+    cb.erc[e] = (row << 16) | (uint32_t)col;
     c.atomic_add_u32(&cb.rptr[row], 1u);
   }
   c.sync();
-  ar.top = top_mark;  // release eflat
   cb.nnz_all = nnz;
   return build_cone(c, ar, cb);
+}
+
+CAVE_HD SolveView view_of(const ConeBuild& cb) {
+  SolveView v;
+  v.d = cb.d; v.p = cb.p; v.n_valid = cb.n_valid_proj; v.pm1 = cb.pm1;
+  v.mptr = cb.mptr; v.mcol = cb.mcol; v.mval = cb.mval; v.vkind = cb.vkind;
+  v.cptr = cb.cptr; v.cvar = cb.cvar; v.cvalc = cb.cvalc; v.usign = cb.usign;
+  v.nlong = 0; v.longrow = nullptr;
+  return v;
 }
 
 // Solve + epilogue for one instance whose SolveView is ready.  y must be loaded.
@@ -145,7 +153,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, 
     uint8_t* lflag = ar.get<uint8_t>(p > 0 ? p : 1);
     uint32_t* llist = ar.get<uint32_t>(p > 0 ? p : 1);
     if (ar.ovf) return ST_TOO_LARGE;
-    for (int i = c.tid(); i < p; i += C::NT) lflag[i] = (uint8_t)((v.mhi[i] - v.mlo[i]) > kLongRow ? 1 : 0);
+    for (int i = c.tid(); i < p; i += C::NT) lflag[i] = (uint8_t)((v.mptr[i + 1] - v.mptr[i]) > kLongRow ? 1 : 0);
     c.sync();
     SolveView vv = v;
     vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
@@ -187,10 +195,7 @@ CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P,
       c.sync();
       if (need_avg) compute_avg(c, cb, avg);
       ar.release_top();  // build-phase temporaries (row tags, unit counts, pair scratch) are dead now
-      SolveView v;
-      v.d = d; v.p = cb.p; v.n_valid = cb.n_valid_proj;
-      v.mlo = cb.mlo; v.mhi = cb.mhi; v.ecol = cb.ecol; v.eval = cb.eval; v.vkind = cb.vkind;
-      v.cptr = cb.cptr; v.cvar = cb.cvar; v.cvalc = cb.cvalc; v.usign = cb.usign;
+      SolveView v = view_of(cb);
       CAVE_ACC(1);
       st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
       CAVE_ACC(9);
@@ -234,26 +239,26 @@ CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, i
         S.avg[slot * d + k] = avg[k];
       }
       for (int k = c.tid(); k <= d; k += NT) S.cptr[slot * (d + 1) + k] = cb.cptr[k];
-      // compact CSR of the reduced rows (rows keep their order)
-      uint32_t run = 0;
-      for (int i = 0; i < cb.p; ++i) {
-        uint32_t lo = cb.mlo[i], hi = cb.mhi[i];
-        for (uint32_t e = lo + c.tid(); e < hi; e += NT) {
-          S.ccol[z0 + run + (e - lo)] = cb.ecol[e];
-          S.cval[z0 + run + (e - lo)] = cb.eval[e];
-        }
-        if (c.tid() == 0) {
-          S.rlo[r0 + i] = run;
-          S.rhi[r0 + i] = run + (hi - lo);
-          S.vkind[r0 + i] = cb.vkind[i];
-        }
-        run += hi - lo;
+      // reduced rows: extents, kinds, CSR entries (values expanded from the sign bit in +-1 mode)
+      for (int i = c.tid(); i < cb.p; i += NT) {
+        S.rlo[r0 + i] = cb.mptr[i];
+        S.rhi[r0 + i] = cb.mptr[i + 1];
+        S.vkind[r0 + i] = cb.vkind[i];
       }
       for (uint32_t e = c.tid(); e < cb.nnzM; e += NT) {
-        S.cvar[z0 + e] = cb.cvar[e];
-        S.cvalc[z0 + e] = cb.cvalc[e];
+        const uint32_t x = cb.mcol[e];
+        S.ccol[z0 + e] = (uint16_t)(cb.pm1 ? (x & 0x7fffu) : x);
+        S.cval[z0 + e] = cb.pm1 ? ((x & 0x8000u) ? -1.0f : 1.0f) : cb.mval[e];
       }
-      if (c.tid() == 0) S.n_valid[slot] = cb.n_valid_proj;
+      for (uint32_t e = c.tid(); e < cb.nnzM; e += NT) {
+        const uint32_t x = cb.cvar[e];
+        S.cvar[z0 + e] = (uint16_t)(cb.pm1 ? (x & 0x7fffu) : x);
+        S.cvalc[z0 + e] = cb.pm1 ? ((x & 0x8000u) ? -1.0f : 1.0f) : cb.cvalc[e];
+      }
+      if (c.tid() == 0) {
+        S.n_valid[slot] = cb.n_valid_proj;
+        S.flags[slot] = (uint8_t)(cb.pm1 ? 1 : 0);
+      }
     }
   }
   if (c.tid() == 0 && P.status) P.status[b] = st;
@@ -280,13 +285,13 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
     float* avg = need_avg ? ar.get<float>(d) : nullptr;
     uint8_t* usign = ar.get<uint8_t>(d);
     uint32_t* cptr = ar.get<uint32_t>(d + 1);
-    uint32_t* mlo = ar.get<uint32_t>(p > 0 ? p : 1);
-    uint32_t* mhi = ar.get<uint32_t>(p > 0 ? p : 1);
+    const bool pm1 = (S.flags[slot] & 1) != 0;
+    uint32_t* mptr = ar.get<uint32_t>((uint32_t)p + 1u);
     uint8_t* vkind = ar.get<uint8_t>(p > 0 ? p : 1);
-    uint16_t* ecol = ar.get<uint16_t>(nz > 0 ? nz : 1);
-    float* eval = ar.get<float>(nz > 0 ? nz : 1);
+    uint16_t* mcol = ar.get<uint16_t>(nz > 0 ? nz : 1);
     uint16_t* cvar = ar.get<uint16_t>(nz > 0 ? nz : 1);
-    float* cvalc = ar.get<float>(nz > 0 ? nz : 1);
+    float* mval = pm1 ? nullptr : ar.get<float>(nz > 0 ? nz : 1);
+    float* cvalc = pm1 ? nullptr : ar.get<float>(nz > 0 ? nz : 1);
     if (ar.ovf) st = ST_TOO_LARGE;
     else {
       for (int k = c.tid(); k < d; k += NT) {
@@ -297,22 +302,28 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
       if (need_proj) {
         for (int k = c.tid(); k <= d; k += NT) cptr[k] = S.cptr[slot * (d + 1) + k];
         for (int i = c.tid(); i < p; i += NT) {
-          mlo[i] = S.rlo[r0 + i];
-          mhi[i] = S.rhi[r0 + i];
+          mptr[i] = S.rlo[r0 + i];
           vkind[i] = S.vkind[r0 + i];
         }
+        if (c.tid() == 0) mptr[p] = nz;
         for (uint32_t e = c.tid(); e < nz; e += NT) {
-          ecol[e] = S.ccol[z0 + e];
-          eval[e] = S.cval[z0 + e];
-          cvar[e] = S.cvar[z0 + e];
-          cvalc[e] = S.cvalc[z0 + e];
+          if (pm1) {
+            mcol[e] = (uint16_t)(S.ccol[z0 + e] | (S.cval[z0 + e] < 0.f ? 0x8000u : 0u));
+            cvar[e] = (uint16_t)(S.cvar[z0 + e] | (S.cvalc[z0 + e] < 0.f ? 0x8000u : 0u));
+          } else {
+            mcol[e] = S.ccol[z0 + e];
+            mval[e] = S.cval[z0 + e];
+            cvar[e] = S.cvar[z0 + e];
+            cvalc[e] = S.cvalc[z0 + e];
+          }
         }
       }
       c.sync();
       SolveView v;
-      v.d = d; v.p = p; v.n_valid = S.n_valid[slot];
-      v.mlo = mlo; v.mhi = mhi; v.ecol = ecol; v.eval = eval; v.vkind = vkind;
+      v.d = d; v.p = p; v.n_valid = S.n_valid[slot]; v.pm1 = pm1;
+      v.mptr = mptr; v.mcol = mcol; v.mval = mval; v.vkind = vkind;
       v.cptr = cptr; v.cvar = cvar; v.cvalc = cvalc; v.usign = usign;
+      v.nlong = 0; v.longrow = nullptr;
       st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
     }
   }
@@ -329,20 +340,21 @@ static constexpr uint32_t kMaxLds = 160u * 1024u;
 
 // Upper bound of the arena a dense launch needs, assuming at most `rows_raw` general rows,
 // `p` reduced rows and `nnzM` reduced non-zeros (the kernel reports ST_TOO_LARGE otherwise).
-static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int64_t rows_raw, int64_t p, int64_t nnzM) {
+// `nt` = threads per workgroup (per-thread dump slots of the scan), `pm1` = +-1 cones (no value arrays).
+static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int64_t rows_raw, int64_t p, int64_t nnzM,
+                                         int64_t nt = 256, bool pm1 = false) {
   // bottom: persistent through the solve
-  uint64_t persist = align8u(2 * cap) + align8u(4 * cap + 1024) + align8u(d) + align8u(4 * (d + 1))   // ecol, eval, usign, cptr
-                     + 2 * align8u(4 * p) + align8u(p) + align8u(2 * nnzM) + align8u(4 * nnzM);  // mlo, mhi, vkind, CSC
-  // top: build-phase temporaries
-  uint64_t scan_temps = align8u(4 * (m + 1)) + align8u(4 * cap + 1024);               // rptr, eflat (scan only)
-  uint64_t temps = align8u(4 * (m + 1)) + align8u(4 * d) + align8u(m)                 // rptr, ucnt, rowtag
-                   + 3 * align8u(4 * rows_raw) + align8u(rows_raw)                     // vraw, vnorm, twin, keep
-                   + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // hashes | fill
-  uint64_t vecs = 2 * align8u(4 * d);                                                 // y, avg
-  uint64_t solve = 3 * align8u(8 * d) + align8u(d)                                    // res, tvec/q, rc, dflag
+  uint64_t persist = align8u(d) + align8u(4 * (d + 1)) + align8u(4 * (p + 1)) + align8u(p)       // usign, cptr, mptr, vkind
+                     + 2 * align8u(2 * nnzM) + (pm1 ? 0 : 2 * align8u(4 * nnzM));               // mcol, cvar (+ mval, cvalc)
+  // top: scan output + build-phase temporaries
+  uint64_t scan = 2 * align8u(4 * (cap + nt)) + align8u(4 * (m + 1));                            // erc, eall, rptr
+  uint64_t temps = align8u(4 * d) + align8u(4 * m) + align8u(m) + align8u(4 * (cap / 64 + 1))    // ucnt, rs2, rowtag, long rows
+                   + 3 * align8u(4 * rows_raw) + align8u(rows_raw) + align8u(2 * m)               // vraw, vnorm, twin, keep, rowvar
+                   + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // signatures | fill
+  uint64_t vecs = 2 * align8u(4 * d);                                                            // y, avg
+  uint64_t solve = 3 * align8u(8 * d) + align8u(d)                                               // res, tvec/q, rc, dflag
                    + 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, H, act, long rows
-  if (scan_temps > temps) temps = scan_temps;
-  uint64_t build_peak = persist + temps + vecs;
+  uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
 }
@@ -377,11 +389,11 @@ static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& l
 
 static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz) {
   uint64_t s = 0;
-  s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
-  s += 2 * align8u(4 * (int64_t)max_rows) + align8u(max_rows);                           // mlo, mhi, vkind
-  s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC
-  s += align8u(8 * d) * 3 + align8u(d);                                                  // res, tvec, rc, dflag
   int64_t p = max_rows;
+  s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
+  s += align8u(4 * (p + 1)) + align8u(p);                                               // mptr, vkind
+  s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC (general values)
+  s += align8u(8 * d) * 3 + align8u(d);                                                  // res, tvec, rc, dflag
   s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
   if (s > kMaxLds) return -1;
   return (int32_t)s;

@@ -74,6 +74,7 @@ struct BlockCtx {
   }
   __device__ __forceinline__ double team_reduce_sum(double v) const { return quad_sum_f64(v); }
   __device__ __forceinline__ void atomic_add_u32(uint32_t* p, uint32_t v) const { atomicAdd(p, v); }
+  __device__ __forceinline__ uint32_t atomic_inc_ret_u32(uint32_t* p) const { return atomicAdd(p, 1u); }
   __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }
 
   // publish this wave's count, return (sum over lower waves, total)

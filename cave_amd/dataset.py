@@ -83,6 +83,7 @@ class ConeStore:
         t = self.t
         t["row_off"], t["nnz_off"] = row_off, nnz_off
         t["n_valid"] = torch.zeros(N, dtype=torch.int32, device=dev)
+        t["flags"] = torch.zeros(N, dtype=torch.uint8, device=dev)
         t["usign"] = torch.zeros(N * d, dtype=torch.uint8, device=dev)
         t["avg"] = torch.zeros(N * d, dtype=torch.float32, device=dev)
         t["vkind"] = torch.zeros(max(R, 1), dtype=torch.uint8, device=dev)

@@ -33,10 +33,9 @@ def _as_device(t: torch.Tensor, device: torch.device) -> torch.Tensor:
 
 
 def _grow_limits(m: int, d: int) -> tuple[int, int]:
-    """Largest arena a workgroup can have (160 KiB) and the nnz capacity that fits in it."""
-    other = 4 * (m + 1) + 4 * d + d + m + 4 * (d + 1) + 12 * d + 16 * d + 512
-    reserve = 8 * 64 * 65 + 6 * 8 * 64 + 40 * min(m, 512)  # H for p = 64 + p-vectors + row lists
-    cap = max(64, (_lib.MAX_LDS - other - reserve) // 12)  # 6 B CSR + 6 B CSC per entry
+    """Largest arena a workgroup can have (160 KiB) and a non-zero capacity that leaves room for the
+    rest: the scan output (8 B per non-zero) is a build-phase temporary, so it may take about half."""
+    cap = int(_lib.MAX_LDS * 0.55) // 8 - 256
     return int(min(cap, max(m * d, 64))), _lib.MAX_LDS
 
 

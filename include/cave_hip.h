@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 2
+#define CAVE_HIP_ABI_VERSION 3
 
 /* return codes */
 #define CAVE_OK 0
@@ -100,6 +100,7 @@ int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t
 /* Packed store: structure-of-arrays, all device pointers, filled by cave_hip_pack_fill.
  *   row_off [n+1], nnz_off [n+1]  exclusive prefix sums of the pass-1 counts (int64)
  *   n_valid [n]        rows kept by the projection (0 = empty cone)
+ *   flags   [n]        bit0: every reduced-row entry is +-1 (kernels then keep signs in the indices)
  *   usign   [n*d]      bit0: a +e_k row exists, bit1: a -e_k row exists
  *   avg     [n*d]      _average_ctrs of the instance (static, precomputed)
  *   vkind   [R]        1 = free multiplier (a +a/-a pair), 0 = non-negative     R = row_off[n]
@@ -115,6 +116,7 @@ typedef struct cave_cone_store {
   const int64_t* row_off;
   const int64_t* nnz_off;
   int32_t* n_valid;
+  uint8_t* flags;
   uint8_t* usign;
   float* avg;
   uint8_t* vkind;

@@ -9,10 +9,12 @@ lib = _lib.load()
 ctrs, costs, _ = synth.tsp_batch(20, 1024, seed=0)
 c = torch.tensor(ctrs, device="cuda"); p = torch.tensor(costs, device="cuda")
 names = ["scan+build", "load y/avg", "grad+pgn", "hessian", "inner misc (rhs/ratio/matvec/update)", "solve_spd (GJ)", "ls setup + gather q", "ls dphi loop + theta update", "gather r + f", "epilogue(+solve total tail)", "  scan only", "  classify rows", "  pairing", "  var list + CSC"]
-for mode in (0, 2):
+import sys
+WAVES = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+for mode in (0,):
     outs = ("proj","rnorm") if mode==0 else ("loss","grad")
-    for _ in range(3): cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs)
-    o = cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs)
+    for _ in range(3): cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs, waves=WAVES)
+    o = cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs, waves=WAVES)
     buf = (C.c_ulonglong * (16*1024))()
     lib.cave_hip_debug_stamps(buf, 1024)
     a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 16).astype(np.float64)

@@ -40,7 +40,7 @@ def build(asan: bool = False) -> str:
 class Store(C.Structure):
     _fields_ = [
         ("n", C.c_int64), ("d", C.c_int32), ("reserved", C.c_int32),
-        ("row_off", C.c_void_p), ("nnz_off", C.c_void_p), ("n_valid", C.c_void_p),
+        ("row_off", C.c_void_p), ("nnz_off", C.c_void_p), ("n_valid", C.c_void_p), ("flags", C.c_void_p),
         ("usign", C.c_void_p), ("avg", C.c_void_p), ("vkind", C.c_void_p),
         ("rlo", C.c_void_p), ("rhi", C.c_void_p), ("ccol", C.c_void_p), ("cval", C.c_void_p),
         ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),
@@ -84,7 +84,7 @@ class Emul:
         nnz_off = np.concatenate([[0], np.cumsum(n_nnz, dtype=np.int64)]).astype(np.int64)
         R, Z = int(row_off[-1]), int(nnz_off[-1])
         arrs = {
-            "row_off": row_off, "nnz_off": nnz_off, "n_valid": np.zeros(B, np.int32),
+            "row_off": row_off, "nnz_off": nnz_off, "n_valid": np.zeros(B, np.int32), "flags": np.zeros(B, np.uint8),
             "usign": np.zeros(B * d, np.uint8), "avg": np.zeros(B * d, np.float32),
             "vkind": np.zeros(max(R, 1), np.uint8), "rlo": np.zeros(max(R, 1), np.uint32),
             "rhi": np.zeros(max(R, 1), np.uint32), "ccol": np.zeros(max(Z, 1), np.uint16),

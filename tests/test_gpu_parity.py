@@ -117,6 +117,24 @@ def test_full_size_properties_tsp20_b1024(hip):
     assert np.abs(o["proj"][sel] - po).max() <= 4e-6 and np.abs(o["rnorm"][sel] - ro).max() <= 4e-6
 
 
+def test_tsp50_gpu(hip, golden):
+    """BASELINE configs[2] instance size (d = 1225, ~1330 rows, 50-55 reduced rows): one wave per
+    instance with the full 160 KiB arena; the reference's own outputs are the fixture."""
+    from cave_amd import synth
+
+    g = golden["tsp50"]
+    c, y, _ = synth.tsp_batch(int(g["n"]), int(g["batch"]), seed=int(g["seed"]))
+    o = hip(c, -y, MODE_PROJECT, 1.0, 0.0)  # default limits do not fit -> automatic retry (waves=1, max arena)
+    assert (o["status"] == 0).all()
+    assert np.abs(o["proj"] - g["proj"]).max() <= 4e-6 and np.abs(o["rnorm"] - g["rnorm"]).max() <= 4e-6
+    c8, y8, _ = synth.tsp_batch(50, 8, seed=5)
+    from oracle import cave_oracle as O
+
+    o = hip(c8, y8, MODE_EXACT, -1.0, 0.0)
+    t = O.exact_target(-y8, c8)[0]
+    assert np.abs(o["loss"] - O.cone_loss(y8, t, -1.0)).max() <= 2e-6
+
+
 def test_packed_store_equals_dense_gpu():
     import torch
 
