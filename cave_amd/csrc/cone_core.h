@@ -35,6 +35,7 @@ struct ConeBuild {
   uint8_t* rowtag;   // [m]
   uint32_t* vraw;    // [p_raw] general rows, in row order (both twins of a pair)
   float* vnorm;      // [p_raw] l2 norm of those rows
+  float* vinv;       // [p] 1/norm of the kept UNPAIRED rows that count in _average_ctrs, else 0
   int p_raw;
   // ---- persistent (bottom of the arena): what the solver reads
   uint8_t* usign;    // [d]
@@ -214,6 +215,7 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   const int p = cb.p;
   cb.mptr = ar.get<uint32_t>((uint32_t)p + 1u);
   cb.vkind = ar.get<uint8_t>(p > 0 ? p : 1);
+  cb.vinv = ar.get_top<float>(p > 0 ? p : 1);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int r = c.tid(); r < m; r += NT) rowvar[r] = 0xffffu;
   if (c.tid() == 0) cb.mptr[p] = 0u;
@@ -225,6 +227,7 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
     rowvar[r] = (uint16_t)i;
     cb.mptr[i] = cb.rptr[r + 1] - cb.rptr[r];
     cb.vkind[i] = (uint8_t)(keep[src] == 2 ? 1 : 0);
+    cb.vinv[i] = (keep[src] != 2 && (cb.rowtag[r] & ROW_AVG_VALID)) ? 1.0f / fmaxf(cb.vnorm[src], (float)kNormClamp) : 0.f;
     notpm1 += (cb.rowtag[r] & ROW_PM1) ? 0u : 1u;
   }
   notpm1 = c.reduce_add_u32(notpm1);
@@ -291,21 +294,23 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   return ST_OK;
 }
 
-// Per-instance average of unit-normalised valid rows (src/cave.py:222-228).
+// Per-instance average of unit-normalised valid rows (src/cave.py:222-228), one thread per
+// coordinate over the CSC of the reduced rows.  The two rows of a +a/-a pair contribute
+// a/|a| - a/|a| = 0 and are skipped (the reference adds and subtracts them in float32, which
+// leaves round-off of the order of 1e-8); they still count in the number of valid rows.
 template <class C>
 CAVE_HD void compute_avg(C& c, const ConeBuild& cb, float* avg) {
-  const int NT = C::NT;
-  for (int k = c.tid(); k < cb.d; k += NT) avg[k] = (float)(cb.ucnt[k] & 0xffffu) - (float)(cb.ucnt[k] >> 16);
-  c.sync();
-  for (int i = 0; i < cb.p_raw; ++i) {
-    uint32_t r = cb.vraw[i];
-    if (!(cb.rowtag[r] & ROW_AVG_VALID)) continue;  // uniform
-    float inv = 1.0f / fmaxf(cb.vnorm[i], (float)kNormClamp);
-    for (uint32_t e = cb.rptr[r] + c.tid(); e < cb.rptr[r + 1]; e += NT) avg[cb.erc[e] & 0xffffu] += cb.eall[e] * inv;
-    c.sync();
+  const float invn = 1.0f / (float)(cb.n_valid_avg > 1 ? cb.n_valid_avg : 1);
+  for (int k = c.tid(); k < cb.d; k += C::NT) {
+    float a = (float)(cb.ucnt[k] & 0xffffu) - (float)(cb.ucnt[k] >> 16);
+    for (uint32_t e = cb.cptr[k]; e < cb.cptr[k + 1]; ++e) {
+      const uint32_t x = cb.cvar[e];
+      const uint32_t var = cb.pm1 ? (x & 0x7fffu) : x;
+      const float val = cb.pm1 ? ((x & 0x8000u) ? -1.0f : 1.0f) : cb.cvalc[e];
+      a += val * cb.vinv[var];
+    }
+    avg[k] = a * invn;
   }
-  float invn = 1.0f / (float)(cb.n_valid_avg > 1 ? cb.n_valid_avg : 1);
-  for (int k = c.tid(); k < cb.d; k += NT) avg[k] *= invn;
   c.sync();
 }
 
@@ -416,6 +421,48 @@ CAVE_HD void dphi(C& c, const SolveView& v, const double* r, const double* q, do
   }
   *d1 = c.reduce_sum(a1);
   *d2 = c.reduce_sum(a2);
+}
+
+// theta += alpha * dv with exact zeros for variables parked at / blocked by a bound
+template <class C>
+CAVE_HD void update_theta(C& c, const SolveView& v, double* theta, const double* tc, const double* dv, double alpha,
+                          double amax) {
+  for (int i = c.tid(); i < v.p; i += C::NT) {
+    double t = theta[i] + alpha * dv[i];
+    if (!v.vkind[i]) {
+      if ((alpha == 1.0 && tc[i] == 0.0) || t < 0.0 ||
+          (alpha >= amax && dv[i] < 0.0 && theta[i] <= -amax * dv[i] * (1.0 + 1e-12)))
+        t = 0.0;
+    }
+    theta[i] = t;
+  }
+  c.sync();
+}
+
+// Safeguarded 1-D Newton iteration for the root of phi'(alpha) (monotone, piecewise linear) on
+// [0, amax], started at the full step alpha = 1.  eval(alpha, d1, d2) returns phi' and phi''.
+template <class EVAL>
+CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
+  double alpha = 1.0, lo = 0.0, hi = amax, d1 = 0.0, d2 = 0.0;
+  const double psitol = 1e-12 * fabs(psi0);
+  for (int ls = 0; ls < 60; ++ls) {
+    eval(alpha, d1, d2);
+#ifdef CAVE_TRACE
+    printf("   ls %d alpha %.6e psi %.3e (psi0 %.3e) curv %.3e  [%g, %g]\n", ls, alpha, d1, psi0, d2, lo, hi);
+#endif
+    if (fabs(d1) <= psitol) break;
+    if (d1 < 0.0) {
+      lo = alpha;
+      if (alpha >= amax) break;  // a bound blocks: stay at the end of the segment
+    } else hi = alpha;
+    double an = (d2 > 0.0) ? alpha - d1 / d2 : (d1 < 0.0 ? 2.0 * alpha : 0.5 * (lo + alpha));
+    if (hi < 1e299) { if (!(an > lo && an < hi)) an = 0.5 * (lo + hi); }
+    else if (!(an > lo)) an = 2.0 * alpha;
+    if (an > amax) an = amax;
+    if (hi - lo <= 1e-15 * hi) break;
+    alpha = an;
+  }
+  return alpha;
 }
 
 // One Newton step = exact minimisation of the local quadratic model over the
@@ -577,45 +624,82 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     if (amax < 1.0) amax = 1.0;
     c.sync();
     if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n); break; }
-    gather_mt<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);  // q = M^T dv, so r(alpha) = r - alpha q
-    CAVE_ACC(6);
-    double alpha = 1.0, lo = 0.0, hi = amax;
-    double d1, d2;
-    const double psitol = 1e-12 * fabs(psi0);
-    for (int ls = 0; ls < 60; ++ls) {
-      dphi(c, v, r, w.q, alpha, &d1, &d2);
-#ifdef CAVE_TRACE
-      printf("   ls %d alpha %.6e psi %.3e (psi0 %.3e) curv %.3e  [%g, %g]\n", ls, alpha, d1, psi0, d2, lo, hi);
-#endif
-      if (fabs(d1) <= psitol) break;
-      if (d1 < 0.0) {
-        lo = alpha;
-        if (alpha >= amax) break;  // a bound blocks: stay at the end of the segment
-      } else hi = alpha;
-      double an = (d2 > 0.0) ? alpha - d1 / d2 : (d1 < 0.0 ? 2.0 * alpha : 0.5 * (lo + alpha));
-      if (hi < 1e299) { if (!(an > lo && an < hi)) an = 0.5 * (lo + hi); }
-      else if (!(an > lo)) an = 2.0 * alpha;
-      if (an > amax) an = amax;
-      if (hi - lo <= 1e-15 * hi) break;
-      alpha = an;
-    }
-    for (int i = c.tid(); i < p; i += NT) {
-      double t = theta[i] + alpha * w.dv[i];
-      if (!v.vkind[i]) {
-        // variables the inner loop parked at a bound, or that block the extended step, sit at exactly 0
-        if ((alpha == 1.0 && tc[i] == 0.0) || t < 0.0 || (alpha >= amax && w.dv[i] < 0.0 && theta[i] <= -amax * w.dv[i] * (1.0 + 1e-12))) t = 0.0;
+    // q = M^T dv, so r(alpha) = r - alpha q.  When the cost dimension fits KREG coordinates per
+    // thread, q and r stay in registers for the whole search and the residual update is fused in.
+    double alpha, fn;
+    bool fast = false;
+    if constexpr (C::KREG > 0) fast = d <= C::KREG * NT;
+    if (fast) {
+      constexpr int K = C::KREG > 0 ? C::KREG : 1;
+      double rk[K], qk[K];
+      uint8_t uk[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int k = c.tid() + j * NT;
+        rk[j] = 0.0; qk[j] = 0.0; uk[j] = 3;
+        if (k < d) {
+          rk[j] = r[k];
+          uk[j] = v.usign[k];
+          double q = 0.0;
+          for (uint32_t e = v.cptr[k]; e < v.cptr[k + 1]; ++e) {
+            uint32_t var;
+            double val;
+            csc_entry<PM1>(v, e, var, val);
+            q += val * w.dv[var];
+          }
+          qk[j] = q;
+        }
       }
-      theta[i] = t;
+      CAVE_ACC(6);
+      alpha = exact_step([&](double a, double& d1, double& d2) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          double t = clip_unit(rk[j] - a * qk[j], uk[j]);
+          if (t != 0.0) { a1 -= t * qk[j]; a2 += qk[j] * qk[j]; }
+        }
+        c.reduce_sum2(a1, a2);
+        d1 = a1; d2 = a2;
+      }, psi0, amax);
+      CAVE_ACC(7);
+      const bool fresh = (it & 7) == 7;  // periodic fresh residual bounds the drift of the increments
+      double acc = 0.0;
+      if (!fresh) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int k = c.tid() + j * NT;
+          if (k < d) {
+            const double rn = rk[j] - alpha * qk[j];
+            const double t = clip_unit(rn, uk[j]);
+            r[k] = rn;
+            rc[k] = t;
+            acc += t * t;
+          }
+        }
+      }
+      update_theta(c, v, theta, tc, w.dv, alpha, amax);
+      if (fresh) {
+        gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+        fn = refresh_clipped(c, v, r, rc);
+      } else {
+        fn = 0.5 * c.reduce_sum(acc);
+        c.sync();
+      }
+      CAVE_ACC(8);
+    } else {
+      gather_mt<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
+      CAVE_ACC(6);
+      alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
+      update_theta(c, v, theta, tc, w.dv, alpha, amax);
+      CAVE_ACC(7);
+      if ((it & 7) == 7) gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+      else {
+        for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
+        c.sync();
+      }
+      fn = refresh_clipped(c, v, r, rc);
+      CAVE_ACC(8);
     }
-    c.sync();
-    CAVE_ACC(7);
-    if ((it & 7) == 7) gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);  // periodic fresh residual bounds the drift
-    else {
-      for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
-      c.sync();
-    }
-    double fn = refresh_clipped(c, v, r, rc);
-    CAVE_ACC(8);
     // An exact line search along the Newton direction that no longer lowers f beyond
     // round-off means the Newton decrement is ~0: by the projection inequality
     // ||proj - proj*||^2 <= 2 (f - f*), so this is fp32-exact long before it triggers.

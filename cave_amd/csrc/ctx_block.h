@@ -20,6 +20,7 @@ struct BlockCtx {
   static constexpr int TEAM = 4;
   static constexpr int SCAN_UNROLL = 4;  // 4 x 1 KiB per wave per batch, two batches in flight
   static constexpr int PMAX = 32;        // register budget at 4 waves/SIMD: 128 VGPRs
+  static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
   struct Scratch {
     double f64[2][8];
     uint32_t u32[2][8];
@@ -51,6 +52,18 @@ struct BlockCtx {
     for (int i = 0; i < NW; ++i) s += sc->f64[par][i];
     par ^= 1u;
     return s;
+  }
+  // two sums for the price of one barrier (needs NW <= 4: slots wave and 4 + wave)
+  __device__ __forceinline__ void reduce_sum2(double& a, double& b) {
+    static_assert(NW <= 4, "reduce_sum2 uses 2*NW scratch slots");
+    double wa = wave_sum_f64(a), wb = wave_sum_f64(b);
+    if (lane == 0) { sc->f64[par][wave] = wa; sc->f64[par][4 + wave] = wb; }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { sa += sc->f64[par][i]; sb += sc->f64[par][4 + i]; }
+    par ^= 1u;
+    a = sa; b = sb;
   }
   __device__ __forceinline__ double reduce_max(double v) {
     double w = wave_max_f64(v);

@@ -14,6 +14,7 @@ struct WaveCtx {
   static constexpr int TEAM = 4;         // lanes sharing one CSR row in gradient()
   static constexpr int SCAN_UNROLL = 8;  // 8 x 1 KiB dwordx4 loads per batch, two batches in flight
   static constexpr int PMAX = 64;        // largest reduced system solve_spd holds in registers
+  static constexpr int KREG = 4;         // line search keeps r, q in registers when d <= KREG * NT
   static constexpr uint32_t SCRATCH_BYTES = 0;
   int lane;
 #ifdef CAVE_STAMPS
@@ -23,6 +24,7 @@ struct WaveCtx {
   __device__ __forceinline__ int tid() const { return lane; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ double reduce_sum(double v) const { return wave_sum_f64(v); }
+  __device__ __forceinline__ void reduce_sum2(double& a, double& b) const { a = wave_sum_f64(a); b = wave_sum_f64(b); }
   __device__ __forceinline__ double team_reduce_sum(double v) const { return quad_sum_f64(v); }
   __device__ __forceinline__ double reduce_max(double v) const { return wave_max_f64(v); }
   __device__ __forceinline__ uint32_t reduce_add_u32(uint32_t v) const { return wave_sum_u32(v); }

@@ -13,6 +13,8 @@ struct SerialCtx {
   static constexpr int NT = 1;
   static constexpr int TEAM = 1;
   static constexpr uint32_t SCRATCH_BYTES = 0;
+  static constexpr int KREG = 0;  // always the LDS (memory) form of the line search
+  void reduce_sum2(double&, double&) const {}
   double team_reduce_sum(double v) const { return v; }
   static constexpr int PMAX = 64;
   int tid() const { return 0; }
