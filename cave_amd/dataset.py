@@ -105,13 +105,22 @@ class ConeStore:
                                               stream), "cave_hip_pack_fill")
             _raise_for_status(status, "ConeStore fill")
             slot += B
-        self.waves = 4 if self.max_rows <= 32 else 1  # 4-wave workgroups hold reduced systems up to 32 rows
+        self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
+        self.waves = 0  # 0 = choose per call
         self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz))
         if self.lds_bytes <= 0:
             raise RuntimeError("ConeStore: largest instance does not fit a 160 KiB LDS arena")
         return self
 
     # -------------------------------------------------------------------- use
+    def _waves_for(self, B: int) -> int:
+        """4 cooperating waves per instance shorten the critical path while the GPU has idle SIMDs
+        (about one instance per SIMD: B <= ~1024 on 256 CUs); beyond that one wave per instance gives
+        more instances in flight and wins on throughput (measured crossover between 1024 and 2048)."""
+        if self.waves in (1, 4):
+            return self.waves if (self.waves == 1 or self.fits4) else 1
+        return 4 if (self.fits4 and B <= 1280) else 1
+
     def nbytes(self) -> int:
         return sum(v.numel() * v.element_size() for v in self.t.values())
 
@@ -143,7 +152,7 @@ class ConeStore:
                 return out
             rc = lib.cave_hip_cone_packed(
                 C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                int(max_iter), self.lds_bytes, self.waves,
+                int(max_iter), self.lds_bytes, self._waves_for(B),
                 _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                 _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                 _lib.current_stream())

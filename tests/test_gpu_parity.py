@@ -200,3 +200,18 @@ def test_modules_autograd_reduction_and_branching(golden):
     # _get_projection API parity (test_func.py:288)
     t = exactConeAlignedCosine(M(EPO.MINIMIZE), solver="hip")._get_projection(-costs.cuda(), ctrs.cuda())
     assert np.abs(t.cpu().numpy() - g["generic_min_exact_target"]).max() <= 4e-6
+
+
+def test_training_example_reduces_regret():
+    """BASELINE configs[0] shape (SP 5x5, 100 instances, batch 32) end to end with solver='hip':
+    the loop of code_sample.py:48-60 on Gurobi-free exact cones; dense and packed cone formats."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import train_sp_cave
+
+    for extra in ([], ["--packed"]):
+        hist = train_sp_cave.main(["--epochs", "6", "--num-data", "100", "--batch", "32"] + extra)
+        assert hist[-1][2] < 0.6 * hist[0][2], hist          # regret drops
+        assert hist[-1][1] < hist[1][1], hist                # loss drops
