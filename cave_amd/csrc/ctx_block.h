@@ -19,7 +19,7 @@ struct BlockCtx {
   static constexpr int NT = 64 * NW;
   static constexpr int TEAM = 4;
   static constexpr int SCAN_UNROLL = 4;  // 4 x 1 KiB per wave per batch, two batches in flight
-  static constexpr int PMAX = 32;        // register budget at 4 waves/SIMD: 128 VGPRs
+  static constexpr int PMAX = (NW <= 2) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2
   static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
   struct Scratch {
     double f64[2][8];
@@ -140,7 +140,7 @@ struct BlockCtx {
   // wave 0 solves in registers; the caller's sync() publishes dv to the other waves
   __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                             double reg_rel, double* dv) const {
-    if (wave == 0) gj_solve<32>(lane, H, ldh, g, act, p, reg_rel, dv);
+    if (wave == 0) gj_solve<PMAX>(lane, H, ldh, g, act, p, reg_rel, dv);
   }
 
   // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns

@@ -19,14 +19,18 @@ for B in (256, 1024, 2048, 4096):
     store = ConeStore.from_dense(c)
     ids = torch.arange(B, device="cuda")
     row = []
-    for mi in (1, 3, 100):
+    for mi in (1, 100):
         td = timeit(lambda: cone_op_dense(c, p, 0, -1.0, 0.2, max_iter=mi, check=False))
         td1 = timeit(lambda: cone_op_dense(c, p, 0, -1.0, 0.2, max_iter=mi, waves=1, check=False))
+        td2 = timeit(lambda: cone_op_dense(c, p, 0, -1.0, 0.2, max_iter=mi, waves=2, check=False))
         store.waves = 4
         tp = timeit(lambda: store.cone_op(ids, p, 0, -1.0, 0.2, max_iter=mi, check=False))
         store.waves = 1
         tp1 = timeit(lambda: store.cone_op(ids, p, 0, -1.0, 0.2, max_iter=mi, check=False))
         store.waves = 0
-        row.append((mi, round(td,1), round(td1,1), round(tp,1), round(tp1,1)))
+        store.waves = 2
+        tp2 = timeit(lambda: store.cone_op(ids, p, 0, -1.0, 0.2, max_iter=mi, check=False))
+        store.waves = 0
+        row.append((mi, round(td,1), round(td2,1), round(td1,1), round(tp,1), round(tp2,1), round(tp1,1)))
     ta = timeit(lambda: cone_op_dense(c, None, 4, check=False, outputs=("target",)))
-    print(f"B={B}: (max_iter, dense4 us, dense1 us, packed4 us, packed1 us) {row}  avg-only(scan+build+avg) {ta:.1f} us")
+    print(f"B={B}: (max_iter, dense4, dense2, dense1, packed4, packed2, packed1 us) {row}  avg-only(scan+build+avg) {ta:.1f} us")
