@@ -77,7 +77,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -143,6 +143,13 @@ def main():
     alg_bytes = int((4 * m_i * d).sum() + B * (4 * d + out_bytes))
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    traffic = None  # HBM bytes per launch from the PMC passes (tools/diag/pmc_run.sh -> profiles/)
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        if pm.get("workload") == f"tsp{args.tsp}_b{args.batch}_{args.mode}":
+            traffic = pm.get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        pass
     if rank == 0:
         res = {
             "metric": "cone projections/sec", "value": world * B * args.steps / dt, "unit": "projections/s",
@@ -153,7 +160,7 @@ def main():
                                    f"CaVE+ ({args.mode}) solver='hip', dense (B,m_max,d) wire format",
                        "batch_per_gpu": B, "d": d, "m_max": m_max, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "cone_dense_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
             "newton_iters_mean": float(o["iters"].float().mean()),
         }

@@ -332,11 +332,12 @@ CAVE_HD void csc_entry(const SolveView& v, uint32_t e, uint32_t& var, double& va
 }
 
 CAVE_HD double clip_unit(double r, uint8_t u) {
-  // residual left after the best multipliers of the +e_k / -e_k rows (closed form)
-  if (u == 3) return 0.0;
-  if (u == 1) return fmin(r, 0.0);
-  if (u == 2) return fmax(r, 0.0);
-  return r;
+  // residual left after the best multipliers of the +e_k / -e_k rows (closed form), branch-free:
+  //   r - clamp(r, lo, hi),  lo = -inf if a -e_k row exists else 0,  hi = +inf if a +e_k row exists else 0
+  // (u = 0: r;  u = 1: min(r, 0);  u = 2: max(r, 0);  u = 3: 0;  exact, since the clamp returns r or 0)
+  const double lo = (u & 2) ? -HUGE_VAL : 0.0;
+  const double hi = (u & 1) ? HUGE_VAL : 0.0;
+  return r - fmin(fmax(r, lo), hi);
 }
 
 // out[k] = base[k] - (M^T th)[k]   (base = y, or null for 0);  one CSC gather pass

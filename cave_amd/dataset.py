@@ -114,12 +114,12 @@ class ConeStore:
 
     # -------------------------------------------------------------------- use
     def _waves_for(self, B: int) -> int:
-        """4 cooperating waves per instance shorten the critical path while the GPU has idle SIMDs
-        (about one instance per SIMD: B <= ~1024 on 256 CUs); beyond that one wave per instance gives
-        more instances in flight and wins on throughput (measured crossover between 1024 and 2048)."""
+        """Waves per instance.  Two cooperating waves shorten the critical path while the GPU has idle
+        SIMDs (about one instance per SIMD: B <= ~1024 on 256 CUs); beyond that one wave per instance
+        puts more instances in flight and wins on throughput (measured crossover between 1024 and 2048)."""
         if self.waves in (1, 2, 4):
-            return self.waves if (self.waves != 4 or self.fits4) else 1
-        return 4 if (self.fits4 and B <= 1280) else 1
+            return self.waves if (self.waves != 4 or self.fits4) else 2
+        return 2 if B <= 1280 else 1
 
     def nbytes(self) -> int:
         return sum(v.numel() * v.element_size() for v in self.t.values())

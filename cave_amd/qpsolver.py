@@ -64,8 +64,8 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
 
     tight_ctrs (B, m_max, d) float32 zero-padded (src/dataset.py:143); pred_cost (B, d).
     ``outputs`` selects which of proj / rnorm / target / loss / grad are materialised.
-    ``waves``: wavefronts per instance (0/4: 4-wave workgroups, reduced systems <= 32 rows;
-    1: one wave per instance, <= 64 rows).
+    ``waves``: wavefronts cooperating per instance (0 = library default 2; 1 or 2: reduced systems
+    up to 64 rows; 4: up to 32 rows).
     With ``check=True`` (default) the per-instance status is read back (one host sync):
     a cone that does not fit is retried once with one wave per instance and the largest
     arena, anything else raises.

@@ -64,8 +64,10 @@ int32_t cave_hip_device_count(void);
  * dense block; lds_bytes: dynamic LDS per workgroup (<= 160 KiB).  Pass 0 for
  * either to let the library choose (cave_hip_default_limits reports the
  * choice so a caller can grow it after CAVE_ST_TOO_LARGE).
- * waves: wavefronts per instance.  4 (default when 0 is passed): a 4-wave workgroup
- * per instance, reduced systems up to 32 rows; 1: one wave per instance, up to 64 rows. */
+ * waves: wavefronts cooperating on one instance (workgroup = `waves` x 64 threads).
+ *   0 = library default (2);  1 or 2: reduced systems up to 64 rows;  4: up to 32 rows.
+ * More waves shorten the per-instance critical path (useful while B is about the number of SIMDs,
+ * 1024 on MI355X); one wave per instance maximises instances in flight (best throughput for large B). */
 int32_t cave_hip_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes);
 
 /* Fused per-instance operator on the reference's dense wire format.

@@ -3,7 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from cave_amd import _lib, synth
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcave_hip_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcave_hip_stamps.so")  # built by tools/diag/build_stamps.sh
 from cave_amd.qpsolver import cone_op_dense
 lib = _lib.load()
 ctrs, costs, _ = synth.tsp_batch(20, 1024, seed=0)
