@@ -88,7 +88,7 @@ def load_library() -> C.CDLL:
     lib.cave_hip_pack_fill.argtypes = [vp, i64, i64, i64, i32, i32, i32, C.POINTER(Store), i64, vp, vp]
     lib.cave_hip_cone_packed.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32, i32,
                                          vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.cave_hip_packed_lds_bytes.argtypes = [i64, i32, i32]
+    lib.cave_hip_packed_lds_bytes.argtypes = [i64, i32, i32, i32]
     for name in ("cave_hip_default_limits", "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill",
                  "cave_hip_cone_packed", "cave_hip_packed_lds_bytes"):
         getattr(lib, name).restype = C.c_int32

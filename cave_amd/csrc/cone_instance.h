@@ -364,10 +364,12 @@ static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap,
   int64_t cap = 4 * (m_max + d) + 256;
   if (cap > m_max * d) cap = m_max * d;
   if (cap < 64) cap = 64;
-  uint64_t need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10);
+  // sized for structured cones (+-1 entries, <= 32 reduced rows, <= 64 general rows); a cone that
+  // needs more reports ST_TOO_LARGE and the caller retries with the full 160 KiB arena
+  uint64_t need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10, 256, true);
   while (need > kMaxLds && cap > 256) {
     cap = cap * 3 / 4;
-    need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10);
+    need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10, 256, true);
   }
   if (need > kMaxLds) need = kMaxLds;
   if (nnz_cap) *nnz_cap = (int32_t)cap;
@@ -381,18 +383,18 @@ static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& l
   if (cap <= 0) cap = dcap;
   if (lds <= 0) {
     // honour a caller-supplied nnz_cap when deriving the arena size
-    uint64_t need = arena_bytes_dense(m, d, cap, 64, 32, (int64_t)cap * 6 / 10);
+    uint64_t need = arena_bytes_dense(m, d, cap, 64, 32, (int64_t)cap * 6 / 10, 256, true);
     lds = (int32_t)(need > kMaxLds ? kMaxLds : need);
   }
   return lds > 0 && (uint32_t)lds <= kMaxLds && cap > 0;
 }
 
-static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz) {
+static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false) {
   uint64_t s = 0;
   int64_t p = max_rows;
   s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
   s += align8u(4 * (p + 1)) + align8u(p);                                               // mptr, vkind
-  s += 2 * (align8u(2 * (int64_t)max_nnz) + align8u(4 * (int64_t)max_nnz));             // CSR + CSC (general values)
+  s += 2 * (align8u(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : align8u(4 * (int64_t)max_nnz)));  // CSR + CSC (+ values)
   s += align8u(8 * d) * 3 + align8u(d);                                                  // res, tvec, rc, dflag
   s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
   if (s > kMaxLds) return -1;

@@ -18,7 +18,7 @@ template <int NW>
 struct BlockCtx {
   static constexpr int NT = 64 * NW;
   static constexpr int TEAM = 4;
-  static constexpr int SCAN_UNROLL = 4;  // 4 x 1 KiB per wave per batch, two batches in flight
+  static constexpr int SCAN_UNROLL = (NW <= 2) ? 8 : 4;  // KiB per wave per batch (two batches in flight); VGPR budget
   static constexpr int PMAX = (NW <= 2) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2
   static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
   struct Scratch {

@@ -100,21 +100,23 @@ __device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh
   double b = live ? rhs[lane] : 0.0;
   double diag = 1.0;
   bool dead = !live;
-  const double thresh = 1e-300;
 #pragma unroll
   for (int k = 0; k < PM; ++k) {
     if (k < p) {
-      double piv = readlane_f64(h[k], k);
-      double bk = readlane_f64(b, k);
-      if (piv > thresh) {  // uniform
-        if (lane == k) diag = piv;
-        double fac = (lane == k) ? 0.0 : h[k] / piv;
+      const double piv = readlane_f64(h[k], k);
+      const double bk = readlane_f64(b, k);
+      // reciprocal by v_rcp_f64 + two Newton steps (full double accuracy, a third of the IEEE divide);
+      // a non-positive / NaN pivot (numerically dependent row) gives inv = 0: the row is skipped, x_k = 0
+      const bool ok = piv > 1e-300;
+      double inv = __builtin_amdgcn_rcp(ok ? piv : 1.0);
+      inv = fma(fma(-piv, inv, 1.0), inv, inv);
+      inv = fma(fma(-piv, inv, 1.0), inv, inv);
+      inv = ok ? inv : 0.0;
+      if (lane == k) { diag = ok ? piv : 1.0; dead = dead || !ok; }
+      const double fac = (lane == k) ? 0.0 : h[k] * inv;
 #pragma unroll
-        for (int j = k + 1; j < PM; ++j) h[j] -= fac * readlane_f64(h[j], k);  // columns >= p hold zeros
-        b -= fac * bk;
-      } else if (lane == k) {
-        dead = true;
-      }
+      for (int j = k + 1; j < PM; ++j) h[j] -= fac * readlane_f64(h[j], k);  // columns >= p hold zeros
+      b -= fac * bk;
     }
   }
   if (live) dv[lane] = dead ? 0.0 : b / diag;

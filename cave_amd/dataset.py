@@ -107,7 +107,8 @@ class ConeStore:
             slot += B
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
         self.waves = 0  # 0 = choose per call
-        self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz))
+        self.all_pm1 = bool((t["flags"] & 1).all()) if N else False
+        self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, int(self.all_pm1)))
         if self.lds_bytes <= 0:
             raise RuntimeError("ConeStore: largest instance does not fit a 160 KiB LDS arena")
         return self

@@ -39,6 +39,11 @@ def _grow_limits(m: int, d: int) -> tuple[int, int]:
     return int(min(cap, max(m * d, 64))), _lib.MAX_LDS
 
 
+# shapes (m_max, d) whose cones did not fit the default (structured-cone) arena: go straight to the
+# large limits next time instead of paying a failed launch per call
+_needs_large: set[tuple[int, int]] = set()
+
+
 def _raise_for_status(status: torch.Tensor, what: str) -> None:
     st = status.cpu()
     if bool((st == ST_OK).all()):
@@ -104,9 +109,15 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
                 _lib.current_stream())
             _lib.check(rc, "cave_hip_cone_dense")
 
-        launch(nnz_cap, lds_bytes, waves)
+        auto = lds_bytes == 0
+        if auto and (m, d) in _needs_large:
+            cap, lds = _grow_limits(m, d)
+            launch(max(cap, nnz_cap), lds, 1)
+        else:
+            launch(nnz_cap, lds_bytes, waves)
         if check:
-            if bool((status == ST_TOO_LARGE).any()) and lds_bytes == 0:
+            if bool((status == ST_TOO_LARGE).any()) and auto and (m, d) not in _needs_large:
+                _needs_large.add((m, d))
                 cap, lds = _grow_limits(m, d)
                 launch(max(cap, nnz_cap), lds, 1)
             _raise_for_status(status, "solver='hip'")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 3
+#define CAVE_HIP_ABI_VERSION 4
 
 /* return codes */
 #define CAVE_OK 0
@@ -144,8 +144,9 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
                              int32_t* status, int32_t* iters, void* stream);
 
 /* LDS bytes cave_hip_cone_packed needs for the largest instance of a store
- * (max_rows / max_nnz over instances, from the pass-1 counts). */
-int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz);
+ * (max_rows / max_nnz over instances, from the pass-1 counts).  all_pm1 != 0: every instance has
+ * flags bit0 set, so no value arrays are staged (smaller arena -> more workgroups per CU). */
+int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1);
 
 #ifdef __cplusplus
 }

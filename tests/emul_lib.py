@@ -102,7 +102,8 @@ class Emul:
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         B = len(ids)
         pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
-        lds = self.lib.cave_emul_packed_lds_bytes(C.c_int64(d), C.c_int32(max_rows), C.c_int32(max_nnz))
+        all_pm1 = int(bool((arrs["flags"] & 1).all()))
+        lds = self.lib.cave_emul_packed_lds_bytes(C.c_int64(d), C.c_int32(max_rows), C.c_int32(max_nnz), C.c_int32(all_pm1))
         assert lds > 0
         out = {
             "proj": np.zeros((B, d), np.float32), "rnorm": np.zeros(B, np.float32),

@@ -20,7 +20,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cave_hip_version() == 3
+    assert lib.cave_hip_version() == 4
     assert lib.cave_hip_device_count() >= 0
     assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
 
@@ -37,8 +37,8 @@ def test_default_limits_and_arg_validation():
     assert lib.cave_hip_cone_dense(None, None, 1, 4, 70000, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.cave_hip_cone_dense(None, None, 1, 4, 4, 9, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.cave_hip_cone_dense(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == 0  # B == 0
-    assert lib.cave_hip_packed_lds_bytes(190, 26, 700) > 0
-    assert lib.cave_hip_packed_lds_bytes(190, 5000, 700) == -1
+    assert 0 < lib.cave_hip_packed_lds_bytes(190, 26, 700, 1) < lib.cave_hip_packed_lds_bytes(190, 26, 700, 0)
+    assert lib.cave_hip_packed_lds_bytes(190, 5000, 700, 0) == -1
 
 
 def test_status_codes_match_header():

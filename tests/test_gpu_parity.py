@@ -127,7 +127,7 @@ def test_tsp50_gpu(hip, golden):
     o = hip(c, -y, MODE_PROJECT, 1.0, 0.0)  # default limits do not fit -> automatic retry (waves=1, max arena)
     assert (o["status"] == 0).all()
     assert np.abs(o["proj"] - g["proj"]).max() <= 4e-6 and np.abs(o["rnorm"] - g["rnorm"]).max() <= 4e-6
-    c8, y8, _ = synth.tsp_batch(50, 8, seed=5)
+    c8, y8, _ = synth.tsp_batch(50, 3, seed=5)
     from oracle import cave_oracle as O
 
     o = hip(c8, y8, MODE_EXACT, -1.0, 0.0)

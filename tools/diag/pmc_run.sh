@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof3
+OUT=$R/gpurun_out/prof4
 mkdir -p $OUT
 CMD="python3 $R/bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-extras"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.json 2> $OUT/trace.err || echo "trace failed"

@@ -1,0 +1,86 @@
+"""GPU stress (run on an MI355X): random cones of many shapes, every workgroup shape (1/2/4 waves per
+instance), dense and packed paths, against the CPU oracle; repeated launches must be bit-identical.
+    python tools/fuzz/fuzz_gpu.py [seed] [seconds]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, torch
+from cave_amd import synth
+from cave_amd.qpsolver import cone_op_dense
+from cave_amd.dataset import ConeStore
+from oracle import cave_oracle as O
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+T = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+rng = np.random.default_rng(seed)
+t0 = time.time(); n = 0; bad = 0; nondet = 0; worst = 0.0; nfail = 0; nsaved = 0
+from collections import Counter
+nd_kind = Counter(); st_kind = Counter(); inst_kind = Counter()
+OUTS = ("proj", "rnorm", "target", "loss", "grad")
+while time.time() - t0 < T:
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        nn = int(rng.integers(4, 21)); B = 48
+        A, y, _ = synth.tsp_batch(nn, B, seed=int(rng.integers(1 << 30)))
+    elif kind == 1:
+        h, w = int(rng.integers(2, 7)), int(rng.integers(2, 7)); B = 48
+        A, y, _ = synth.sp_batch(h, w, B, seed=int(rng.integers(1 << 30)))
+    else:
+        d, m, B = int(rng.integers(1, 24)), int(rng.integers(0, 40)), 32
+        A = rng.standard_normal((B, m, d)).astype(np.float32)
+        if kind == 3: A *= rng.random((B, m, d)) < 0.3
+        if kind == 4: A = np.round(A)
+        y = rng.standard_normal((B, d)).astype(np.float32)
+    At, yt = torch.tensor(A, device="cuda"), torch.tensor(y, device="cuda")
+    po, ro = O.batch_project(-y, A)
+    mode = int(rng.integers(0, 3))
+    ref = None
+    for waves in (1, 2, 4):
+        o = cone_op_dense(At, yt, mode, -1.0, 0.2, waves=waves, outputs=OUTS, check=False, lds_bytes=160 * 1024,
+                          nnz_cap=max(64, A.shape[1] * A.shape[2]) if kind >= 2 else 4 * (A.shape[1] + A.shape[2]) + 256)
+        o2 = cone_op_dense(At, yt, mode, -1.0, 0.2, waves=waves, outputs=OUTS, check=False, lds_bytes=160 * 1024,
+                           nnz_cap=max(64, A.shape[1] * A.shape[2]) if kind >= 2 else 4 * (A.shape[1] + A.shape[2]) + 256)
+        stt = o["status"].cpu().numpy()
+        inst_kind[kind] += len(stt)
+        for code in (1, 2, 3): st_kind[(kind, waves, code)] += int((stt == code).sum())
+        if (stt != 0).any():
+            nfail += int((stt != 0).sum())
+            if (stt == 1).any() and nsaved < 5:
+                b = int(np.nonzero(stt == 1)[0][0]); nsaved += 1
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.savez(os.path.join(ROOT, "gpurun_out", f"noconv_{nsaved}.npz"), A=A[b], y=y[b], waves=waves, kind=kind, iters=o["iters"].cpu().numpy()[b])
+                print("NOT CONVERGED kind", kind, A.shape, "waves", waves, "instance", b)
+            ok = stt == 0
+            if waves == 4 and (stt == 2).any(): ok = stt == 0   # p > 32 is legitimately too large for 4 waves
+        else:
+            ok = np.ones(len(stt), bool)
+        keys = ("proj", "rnorm") if mode == 0 else OUTS
+        if not all(torch.equal(o[k], o2[k]) for k in keys):
+            nondet += 1; nd_kind[(kind, waves)] += 1
+            if kind == 1 and nd_kind[(kind, waves)] <= 2:
+                dd = {k: float((o[k] - o2[k]).abs().max()) for k in keys}
+                print('  SP nondeterminism', A.shape, 'waves', waves, 'mode', mode, dd, 'iters differ', int((o['iters'] != o2['iters']).sum()))
+        p = o["proj"].cpu().numpy(); r = o["rnorm"].cpu().numpy()
+        sc = np.maximum(1.0, np.abs(y).max(axis=1))[:, None]
+        if not ok.any(): continue
+        e = max(float((np.abs(p - po) / sc)[ok].max()) if p.size else 0.0, float((np.abs(r - ro) / np.maximum(1, ro))[ok].max()) if r.size else 0.0)
+        worst = max(worst, e)
+        if e > 4e-6:
+            bad += 1
+            if bad <= 5: print("MISMATCH kind", kind, A.shape, "waves", waves, "mode", mode, "err", e)
+
+    if kind in (0, 1):
+        st = ConeStore.from_dense(At)
+        ids = torch.randperm(B, device="cuda")
+        for waves in (1, 2):
+            st.waves = waves
+            o = st.cone_op(ids, yt[ids], mode, -1.0, 0.2, outputs=OUTS, check=False)
+            if bool((o["status"] != 0).any()): nfail += 1; continue
+            p = o["proj"].cpu().numpy()
+            if mode != 3 and np.abs(p - po[ids.cpu().numpy()]).max() > 4e-6 * max(1.0, np.abs(y).max()):
+                bad += 1; print("PACKED MISMATCH", A.shape, waves)
+    n += 1
+print(f"batches {n}  mismatches {bad}  flagged (status != 0) {nfail}  nondeterministic repeats {nondet}  worst rel err {worst:.2e}")
+print("instances per kind (x3 wave configs)", dict(inst_kind)); print("nondeterministic batches per kind", dict(nd_kind)); print("status counts (kind, waves, code)", {k: v for k, v in st_kind.items() if v})
+sys.exit(1 if bad else 0)
