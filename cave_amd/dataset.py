@@ -21,7 +21,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .qpsolver import _raise_for_status
+from .qpsolver import _grow_limits, _raise_for_status
 
 __all__ = ["ConeStore", "PackedBatch", "collate_ids"]
 
@@ -58,18 +58,27 @@ class ConeStore:
         d = int(chunks[0].shape[2])
         self = cls(d, dev)
         stream = _lib.current_stream()
-        # pass 1: counts
-        counts = []
+        # pass 1: counts (default launch limits are sized for small structured cones; a chunk that
+        # does not fit is re-counted with one wave per instance and the full 160 KiB arena)
+        counts, limits = [], []
         for ch in chunks:
             x = ch.to(device=dev, dtype=torch.float32).contiguous()
             B, m, _ = x.shape
             n_rows = torch.empty(B, dtype=torch.int32, device=dev)
             n_nnz = torch.empty(B, dtype=torch.int32, device=dev)
             status = torch.empty(B, dtype=torch.int32, device=dev)
-            _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, 0, 0, 0, _lib.ptr(n_rows), _lib.ptr(n_nnz),
-                                               _lib.ptr(status), stream), "cave_hip_pack_count")
+            lim = (0, 0, 0)
+            for attempt in range(2):
+                _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, lim[0], lim[1], lim[2], _lib.ptr(n_rows),
+                                                   _lib.ptr(n_nnz), _lib.ptr(status), stream), "cave_hip_pack_count")
+                if attempt == 0 and bool((status == _lib.ST_TOO_LARGE).any()):
+                    cap, lds = _grow_limits(m, d)
+                    lim = (cap, lds, 1)
+                    continue
+                break
             _raise_for_status(status, "ConeStore pack")
             counts.append((n_rows, n_nnz))
+            limits.append(lim)
         n_rows = torch.cat([c[0] for c in counts]).to(torch.int64)
         n_nnz = torch.cat([c[1] for c in counts]).to(torch.int64)
         N = int(n_rows.numel())
@@ -97,12 +106,12 @@ class ConeStore:
         self._c = _lib.Store(n=N, d=d, reserved=0, **{k: v.data_ptr() for k, v in t.items()})
         # pass 2: fill
         slot = 0
-        for ch in chunks:
+        for ch, lim in zip(chunks, limits):
             x = ch.to(device=dev, dtype=torch.float32).contiguous()
             B, m, _ = x.shape
             status = torch.empty(B, dtype=torch.int32, device=dev)
-            _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, 0, 0, 0, C.byref(self._c), slot, _lib.ptr(status),
-                                              stream), "cave_hip_pack_fill")
+            _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, lim[0], lim[1], lim[2], C.byref(self._c), slot,
+                                              _lib.ptr(status), stream), "cave_hip_pack_fill")
             _raise_for_status(status, "ConeStore fill")
             slot += B
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
