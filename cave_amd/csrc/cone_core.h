@@ -340,6 +340,12 @@ CAVE_HD double clip_unit(double r, uint8_t u) {
   return r - fmin(fmax(r, lo), hi);
 }
 
+// does coordinate k carry curvature at residual r?  (D_kk of the generalised Hessian: the clip is the
+// identity on u = 0 coordinates, one-sided on u = 1 / 2, and absorbs everything on u = 3)
+CAVE_HD bool active_unit(double r, uint8_t u) {
+  return (u == 0) | ((u == 1) & (r < 0.0)) | ((u == 2) & (r > 0.0));
+}
+
 // out[k] = base[k] - (M^T th)[k]   (base = y, or null for 0);  one CSC gather pass
 template <class C, bool PM1>
 CAVE_HD void gather_mt(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
@@ -417,8 +423,9 @@ CAVE_HD void dphi(C& c, const SolveView& v, const double* r, const double* q, do
   double a1 = 0.0, a2 = 0.0;
   for (int k = c.tid(); k < v.d; k += C::NT) {
     double qk = q[k];
-    double t = clip_unit(r[k] - alpha * qk, v.usign[k]);
-    if (t != 0.0) { a1 -= t * qk; a2 += qk * qk; }
+    const double rr = r[k] - alpha * qk;
+    a1 -= clip_unit(rr, v.usign[k]) * qk;
+    if (active_unit(rr, v.usign[k])) a2 += qk * qk;
   }
   *d1 = c.reduce_sum(a1);
   *d2 = c.reduce_sum(a2);
@@ -522,7 +529,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // generalised Hessian H = M D M^T, D = [Pi(r) != 0]: rank-one updates +-m_k m_k^T for the
     // coordinates whose activity flipped since the previous iteration (all active ones at it 0)
     for (int k = c.tid(); k < d; k += NT) {
-      const uint8_t on = (uint8_t)(rc[k] != 0.0);
+      const uint8_t on = (uint8_t)active_unit(r[k], v.usign[k]);
       if (on == w.dflag[k]) continue;
       w.dflag[k] = on;
       const double sg = on ? 1.0 : -1.0;
@@ -656,8 +663,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         double a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-          double t = clip_unit(rk[j] - a * qk[j], uk[j]);
-          if (t != 0.0) { a1 -= t * qk[j]; a2 += qk[j] * qk[j]; }
+          const double rr = rk[j] - a * qk[j];
+          a1 -= clip_unit(rr, uk[j]) * qk[j];
+          if (active_unit(rr, uk[j])) a2 += qk[j] * qk[j];
         }
         c.reduce_sum2(a1, a2);
         d1 = a1; d2 = a2;
