@@ -225,6 +225,41 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
         train_step()
     torch.cuda.synchronize()
     out["train_step_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+    # the same step captured in a HIP graph (the C-ABI launch path does no allocation, attribute
+    # change or host sync of its own when status checking is deferred)
+    try:
+        reg2 = torch.nn.Linear(p_feat, pred.shape[1]).to(dev)
+        opt2 = torch.optim.Adam(reg2.parameters(), lr=1e-2, capturable=True)
+        cave2 = innerConeAlignedCosine(_Model(), solver="hip", seed=0, solver_kwargs={"check": False})
+
+        def step2():
+            loss = cave2(reg2(x), batch)
+            opt2.zero_grad(set_to_none=False)
+            loss.backward()
+            opt2.step()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step2()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gl = step2()
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            graph.replay()
+        torch.cuda.synchronize()
+        out["train_step_graph_ms"] = 1e3 * (time.perf_counter() - t0) / 100
+        out["train_step_graph_loss"] = float(gl.detach())
+    except Exception as e:  # noqa: BLE001 - graph capture is an optional extra
+        out["train_step_graph_error"] = repr(e)[:200]
     return out
 
 
