@@ -452,7 +452,9 @@ CAVE_HD void update_theta(C& c, const SolveView& v, double* theta, const double*
 template <class EVAL>
 CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
   double alpha = 1.0, lo = 0.0, hi = amax, d1 = 0.0, d2 = 0.0;
-  const double psitol = 1e-12 * fabs(psi0);
+  // an inexact search is enough for the outer Newton iteration: stop once the slope has dropped to a
+  // tenth of its initial value (tighter tolerances cost ~40 % more evaluations for no fewer iterations)
+  const double psitol = 1e-1 * fabs(psi0);
   for (int ls = 0; ls < 60; ++ls) {
     eval(alpha, d1, d2);
 #ifdef CAVE_TRACE
@@ -525,7 +527,10 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     printf("it %d f %.10e pgn %.6e\n", it, f, pgn);
 #endif
     CAVE_ACC(2);
-    if (!(pgn > tol * g0n) || f <= 1e-30 * yy) { converged = true; break; }
+    // Nearly-zero residual (y inside or on the cone): the caller's `rnorm < 1e-7` inside test
+    // (src/cave.py:218) needs rnorm itself resolved, so the gradient test is tightened.
+    const double tol_it = (f < 1e-8 * yy) ? 1e-4 * tol : tol;
+    if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy) { converged = true; break; }
     // generalised Hessian H = M D M^T, D = [Pi(r) != 0]: rank-one updates +-m_k m_k^T for the
     // coordinates whose activity flipped since the previous iteration (all active ones at it 0)
     for (int k = c.tid(); k < d; k += NT) {
