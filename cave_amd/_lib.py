@@ -18,8 +18,8 @@ _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libcave_hip.so")
 _SOURCES = [
     os.path.join(_HERE, "csrc", n)
-    for n in ("cave_hip.hip", "cone_common.h", "cone_core.h", "cone_instance.h", "wave_prims.h", "ctx_wave.h",
-              "ctx_block.h")
+    for n in ("cave_hip.hip", "cone_common.h", "cone_core.h", "cone_band.h", "cone_instance.h", "wave_prims.h",
+              "ctx_wave.h", "ctx_block.h")
 ] + [os.path.join(_ROOT, "include", "cave_hip.h")]
 
 # status / mode constants (include/cave_hip.h)
@@ -31,6 +31,8 @@ ABI_SYMBOLS = (
     "cave_hip_version", "cave_hip_last_error", "cave_hip_device_count", "cave_hip_default_limits",
     "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill", "cave_hip_cone_packed",
     "cave_hip_packed_lds_bytes",
+    "cave_hip_large_slice_bytes", "cave_hip_packed_large_slice_bytes", "cave_hip_cone_dense_large",
+    "cave_hip_pack_large", "cave_hip_cone_packed_large",
 )
 
 
@@ -92,6 +94,17 @@ def load_library() -> C.CDLL:
     for name in ("cave_hip_default_limits", "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill",
                  "cave_hip_cone_packed", "cave_hip_packed_lds_bytes"):
         getattr(lib, name).restype = C.c_int32
+    lib.cave_hip_large_slice_bytes.argtypes = [i64, i64, i64, i64]
+    lib.cave_hip_large_slice_bytes.restype = i64
+    lib.cave_hip_packed_large_slice_bytes.argtypes = [i64, i64, i64]
+    lib.cave_hip_packed_large_slice_bytes.restype = i64
+    lib.cave_hip_cone_dense_large.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i64, i32, vp, i64, i32,
+                                              vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cave_hip_pack_large.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, vp, vp, C.POINTER(Store), i64, vp, vp]
+    lib.cave_hip_cone_packed_large.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32, vp, i64, i32,
+                                               vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in ("cave_hip_cone_dense_large", "cave_hip_pack_large", "cave_hip_cone_packed_large"):
+        getattr(lib, name).restype = C.c_int32
     _lib = lib
     return lib
 
@@ -118,6 +131,32 @@ def default_limits(m_max: int, d: int) -> tuple[int, int]:
     cap, lds = C.c_int32(0), C.c_int32(0)
     check(lib.cave_hip_default_limits(m_max, d, C.byref(cap), C.byref(lds)), "cave_hip_default_limits")
     return int(cap.value), int(lds.value)
+
+
+_workspaces: dict = {}
+
+
+def workspace(device, nbytes: int):
+    """Grow-only per-device scratch buffer for the large-cone path (caller-owned workspace of the C ABI)."""
+    import torch
+
+    t = _workspaces.get(device)
+    if t is None or t.numel() < nbytes:
+        _workspaces.pop(device, None)
+        t = None
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[device] = t
+    return t
+
+
+def large_slots(device, B: int, slice_bytes: int) -> int:
+    """Workgroups (= workspace slices) for a large-cone launch: 4 per CU, bounded by free memory."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info(device)
+    held = _workspaces[device].numel() if device in _workspaces else 0
+    budget = min((free + held) // 2, 64 << 30)
+    return int(max(1, min(B, 1024, budget // max(slice_bytes, 1))))
 
 
 def ptr(t) -> C.c_void_p:

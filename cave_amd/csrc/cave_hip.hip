@@ -75,6 +75,47 @@ __global__ CAVE_BOUNDS(C) void cone_packed_kernel(PackedParams P) {
   }
 }
 
+// ---- large-cone path (cone_band.h): persistent 4-wave workgroups, arena = a slice of a global
+// workspace, LDS = "hot" arena for the small per-iteration arrays.  256 VGPRs (2 waves / SIMD).
+struct LargeWs {
+  unsigned char* base;
+  uint64_t slice;  // bytes per workgroup (< 4 GiB)
+};
+using CtxL = BlockCtx<4>;
+
+__global__ __launch_bounds__(CtxL::NT, 2) void cone_dense_large_kernel(DenseParams P, LargeWs W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CtxL c;
+  c.init(smem);
+  unsigned char* ws = W.base + (uint64_t)blockIdx.x * W.slice;
+  for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
+    run_dense_instance<CtxL, true>(c, smem, P, b, ws, (uint32_t)W.slice);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(CtxL::NT, 2) void cone_pack_large_kernel(PackParams P, LargeWs W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CtxL c;
+  c.init(smem);
+  unsigned char* ws = W.base + (uint64_t)blockIdx.x * W.slice;
+  for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
+    run_pack_instance<CtxL, true>(c, smem, P, b, ws, (uint32_t)W.slice);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(CtxL::NT, 2) void cone_packed_large_kernel(PackedParams P, LargeWs W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CtxL c;
+  c.init(smem);
+  unsigned char* ws = W.base + (uint64_t)blockIdx.x * W.slice;
+  for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
+    run_packed_large_instance<CtxL>(c, smem, P, b, ws, (uint32_t)W.slice);
+    __syncthreads();
+  }
+}
+
 // --------------------------------------------------------------- host helpers
 
 static thread_local char g_err[512] = "";
@@ -227,6 +268,110 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
   P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   CAVE_LAUNCH(cone_packed_kernel, waves, B, lds_bytes, stream, P, "cone_packed_kernel");
+  return CAVE_OK;
+}
+
+// ------------------------------------------------------------------ large-cone path
+
+int64_t cave_hip_large_slice_bytes(int64_t m_max, int64_t d, int64_t nnz_cap, int64_t band_entries) {
+  if (m_max < 0 || d <= 0 || nnz_cap <= 0 || band_entries < 0) return CAVE_E_INVALID;
+  return (int64_t)large_slice_bytes(m_max, d, nnz_cap, band_entries);
+}
+
+int64_t cave_hip_packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band_entries) {
+  if (d <= 0 || max_rows < 0 || band_entries < 0) return CAVE_E_INVALID;
+  return (int64_t)packed_large_slice_bytes(d, max_rows, band_entries);
+}
+
+static int32_t check_large(const char* who, const void* workspace, int64_t slice_bytes, int32_t n_slots, int32_t& lds_bytes) {
+  if (!workspace || slice_bytes < 1024 || slice_bytes >= ((int64_t)1 << 32) || (slice_bytes & 7) || n_slots <= 0 ||
+      ((uintptr_t)workspace & 15u)) {
+    snprintf(g_err, sizeof(g_err), "%s: bad workspace (16-byte aligned, 1 KiB <= slice_bytes < 4 GiB, multiple of 8, n_slots > 0)", who);
+    return CAVE_E_INVALID;
+  }
+  if (lds_bytes <= 0) lds_bytes = 64 * 1024;
+  if (lds_bytes < 1024 || (uint32_t)lds_bytes > kMaxLds) {
+    snprintf(g_err, sizeof(g_err), "%s: bad lds_bytes", who);
+    return CAVE_E_INVALID;
+  }
+  return CAVE_OK;
+}
+
+#define CAVE_LAUNCH_LARGE(KERNEL, B, SLOTS, LDS, STREAM, PARAMS, WS, WHAT)                                      \
+  do {                                                                                                         \
+    hipError_t e_ = ensure_lds(KERNEL, (uint32_t)(LDS));                                                       \
+    if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                     \
+    unsigned grid_ = (unsigned)((B) < (int64_t)(SLOTS) ? (B) : (int64_t)(SLOTS));                              \
+    hipLaunchKernelGGL(KERNEL, dim3(grid_), dim3(CtxL::NT), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS, WS); \
+    e_ = hipGetLastError();                                                                                    \
+    if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "launch " WHAT, e_);                                      \
+  } while (0)
+
+int32_t cave_hip_cone_dense_large(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d,
+                                  int32_t mode, float sign, float inner_ratio, int32_t max_iter, int64_t nnz_cap,
+                                  int32_t lds_bytes, void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj,
+                                  float* rnorm, float* target, float* loss, float* grad, int32_t* status,
+                                  int32_t* iters, void* stream) {
+  if (B < 0 || m_max < 0 || m_max > 65535 || d <= 0 || d > 65535 || m_max * d >= (int64_t)1 << 32)
+    return fail(CAVE_E_INVALID, "cone_dense_large: bad shape (need m_max, d <= 65535, m_max*d < 2^32)");
+  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense_large: bad mode");
+  if (B == 0) return CAVE_OK;
+  if (!ctrs && m_max > 0) return fail(CAVE_E_INVALID, "cone_dense_large: ctrs is null");
+  if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense_large: pred is null");
+  if (nnz_cap <= 0 || nnz_cap >= (int64_t)1 << 31) return fail(CAVE_E_INVALID, "cone_dense_large: bad nnz_cap");
+  int32_t rc = check_large("cone_dense_large", workspace, slice_bytes, n_slots, lds_bytes);
+  if (rc != CAVE_OK) return rc;
+  DenseParams P;
+  P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
+  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
+  P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
+  P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
+  LargeWs W{(unsigned char*)workspace, (uint64_t)slice_bytes};
+  CAVE_LAUNCH_LARGE(cone_dense_large_kernel, B, n_slots, lds_bytes, stream, P, W, "cone_dense_large_kernel");
+  return CAVE_OK;
+}
+
+int32_t cave_hip_pack_large(const float* ctrs, int64_t B, int64_t m_max, int64_t d, int64_t nnz_cap, void* workspace,
+                            int64_t slice_bytes, int32_t n_slots, int32_t* n_rows, int32_t* n_nnz,
+                            const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream) {
+  if (B < 0 || m_max < 0 || m_max > 65535 || d <= 0 || d > 65535 || m_max * d >= (int64_t)1 << 32)
+    return fail(CAVE_E_INVALID, "pack_large: bad shape");
+  if (B == 0) return CAVE_OK;
+  if (!ctrs) return fail(CAVE_E_INVALID, "pack_large: ctrs is null");
+  if (!store && (!n_rows || !n_nnz)) return fail(CAVE_E_INVALID, "pack_large: count pass needs n_rows and n_nnz");
+  if (store && (store->d != d || slot0 < 0 || slot0 + B > store->n)) return fail(CAVE_E_INVALID, "pack_large: store mismatch");
+  if (nnz_cap <= 0 || nnz_cap >= (int64_t)1 << 31) return fail(CAVE_E_INVALID, "pack_large: bad nnz_cap");
+  int32_t lds = 1024;
+  int32_t rc = check_large("pack_large", workspace, slice_bytes, n_slots, lds);
+  if (rc != CAVE_OK) return rc;
+  PackParams P;
+  memset(&P, 0, sizeof(P));
+  P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
+  P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds;
+  P.n_rows = n_rows; P.n_nnz = n_nnz; P.status = status;
+  if (store) { P.store = *store; P.slot0 = slot0; P.fill = 1; }
+  LargeWs W{(unsigned char*)workspace, (uint64_t)slice_bytes};
+  CAVE_LAUNCH_LARGE(cone_pack_large_kernel, B, n_slots, lds, stream, P, W, "cone_pack_large_kernel");
+  return CAVE_OK;
+}
+
+int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
+                                   int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
+                                   void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj, float* rnorm,
+                                   float* target, float* loss, float* grad, int32_t* status, int32_t* iters,
+                                   void* stream) {
+  if (!store || B < 0) return fail(CAVE_E_INVALID, "cone_packed_large: null store / bad B");
+  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed_large: bad mode");
+  if (B == 0) return CAVE_OK;
+  if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed_large: pred is null");
+  int32_t rc = check_large("cone_packed_large", workspace, slice_bytes, n_slots, lds_bytes);
+  if (rc != CAVE_OK) return rc;
+  PackedParams P;
+  P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
+  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
+  P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
+  LargeWs W{(unsigned char*)workspace, (uint64_t)slice_bytes};
+  CAVE_LAUNCH_LARGE(cone_packed_large_kernel, B, n_slots, lds_bytes, stream, P, W, "cone_packed_large_kernel");
   return CAVE_OK;
 }
 

@@ -82,9 +82,19 @@ struct Arena {
     return reinterpret_cast<T*>(base + top);
   }
   CAVE_HD void release_top() { top = cap; }
+  // like get(), but a request that does not fit returns null and leaves the arena untouched
+  template <class T>
+  CAVE_HD T* try_get(uint32_t n) {
+    uint32_t a = (off + 7u) & ~7u;
+    uint64_t e = (uint64_t)a + (uint64_t)n * sizeof(T);
+    if (e > top) return nullptr;
+    off = (uint32_t)e;
+    return reinterpret_cast<T*>(base + a);
+  }
 };
 
-// What the Newton solver needs to know about one cone (all pointers LDS-resident).
+// What the Newton solver needs to know about one cone (LDS-resident on the fast path; the large-cone
+// path points into its global workspace or straight into the packed store).
 struct SolveView {
   int d;                  // cost dimension
   int p;                  // reduced unknowns: one per general row (a +a/-a pair counts once)
@@ -113,10 +123,15 @@ struct SolveWork {
   double* dv;      // [p]  model gradient in the inner loop, then the search direction
   double* g2;      // [p]  right-hand side / H*step scratch
   double* step;    // [p]  Newton step of one inner round
-  double* H;       // [p*ldh]
+  double* H;       // [p*ldh]  dense rows, or (band form) H[j*ldh + t] = H(j+t, j), t = 0..bw, ldh = bw+1
   uint8_t* act;    // [p]
   uint8_t* dflag;  // [d]  coordinates currently counted in H
   int ldh;
+  // band form only (large-cone path, cone_band.h)
+  int bw;          // half bandwidth of M M^T in the reduced-row order
+  double* bwin;    // [(bw+1)*(bw+1)] ring window of the rows being eliminated
+  double* bfac;    // [p*(bw+1)] factor: bfac[k*ldh] = 1/d_k, bfac[k*ldh + t] = row k of the updated band
+  double* bz;      // [p] right-hand side being eliminated
 };
 
 struct SolveResult {

@@ -18,6 +18,7 @@
 //   backtracking on the projection arc).  proj = y - res*, rnorm = ||res*||_2.
 #pragma once
 #include "cone_common.h"
+#include "cone_band.h"
 
 namespace cave {
 
@@ -107,20 +108,20 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
   c.sync();
   const uint32_t nlong = c.compact_mask_u8(cb.rowtag, m, 0xFF, ROW_PENDING, longrows);
   c.sync();
-  for (uint32_t li = 0; li < nlong; ++li) {  // whole team per long row, fixed summation tree
+  for (uint32_t li = (uint32_t)c.wave_id(); li < nlong; li += (uint32_t)C::NWAVES) {  // one wave per long row, fixed tree
     const uint32_t r = longrows[li];
     const uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
     double s1 = 0.0, s2 = 0.0, bad = 0.0;
-    for (uint32_t e = lo + c.tid(); e < hi; e += NT) {
+    for (uint32_t e = lo + (uint32_t)c.lane_id(); e < hi; e += (uint32_t)C::WL) {
       float v = cb.eall[e];
       s1 += (double)fabsf(v);
       s2 += (double)v * (double)v;
       if (fabsf(v) != 1.0f) bad = 1.0;
     }
-    s1 = c.reduce_sum(s1);
-    s2 = c.reduce_sum(s2);
-    bad = c.reduce_max(bad);
-    if (c.tid() == 0) {
+    s1 = c.wave_sum(s1);
+    s2 = c.wave_sum(s2);
+    bad = c.wave_max(bad);
+    if (c.lane_id() == 0) {
       cb.rowtag[r] = classify_row((float)s1, (float)s2, bad == 0.0, hi - lo);
       cb.rs2[r] = (float)s2;
     }
@@ -377,7 +378,7 @@ CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double
 }
 
 // g = -M rc.  Rows are shared by TEAM adjacent lanes (fixed reduction tree); rows longer than
-// kLongRow entries are summed by the whole team of NT lanes, one row at a time.
+// kLongRow entries are summed by one whole wave each.
 
 template <class C, bool PM1>
 CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
@@ -401,18 +402,18 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
     part = c.team_reduce_sum(part);
     if (valid && !is_long && sub == 0) g[i] = part;
   }
-  for (int li = 0; li < v.nlong; ++li) {
+  for (int li = c.wave_id(); li < v.nlong; li += C::NWAVES) {  // one wave per long row
     const int i = (int)v.longrow[li];
     const uint32_t lo = v.mptr[i], hi = v.mptr[i + 1];
     double part = 0.0;
-    for (uint32_t e = lo + c.tid(); e < hi; e += C::NT) {
+    for (uint32_t e = lo + (uint32_t)c.lane_id(); e < hi; e += (uint32_t)C::WL) {
       uint32_t col;
       double val;
       csr_entry<PM1>(v, e, col, val);
       part -= val * rc[col];
     }
-    part = c.reduce_sum(part);
-    if (c.tid() == 0) g[i] = part;
+    part = c.wave_sum(part);
+    if (c.lane_id() == 0) g[i] = part;
   }
   c.sync();
 }
@@ -486,7 +487,10 @@ CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
 // quadratic (no unit rows) the outer loop is a block active-set NNLS method.
 //
 // On return w.res holds the CLIPPED residual Pi(y - M^T theta).
-template <class C, bool PM1>
+//
+// BAND = true (large-cone path): H is kept as a symmetric band (SolveWork::H, ldh = bw + 1) and the
+// model systems are solved by solve_spd_band instead of the register-resident Gauss-Jordan.
+template <class C, bool PM1, bool BAND>
 CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
   const int NT = C::NT;
   const int p = v.p, d = v.d;
@@ -544,12 +548,16 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         double v1, v2;
         csc_entry<PM1>(v, e1, a, v1);
         const double va = sg * v1;
-        c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
+        if constexpr (BAND) c.atomic_add_f64(&w.H[a * ldh], va * v1);
+        else c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
         for (uint32_t e2 = lo; e2 < e1; ++e2) {
           csc_entry<PM1>(v, e2, b, v2);
           double vv = va * v2;
-          c.atomic_add_f64(&w.H[a * ldh + b], vv);
-          c.atomic_add_f64(&w.H[b * ldh + a], vv);
+          if constexpr (BAND) c.atomic_add_f64(&w.H[b * ldh + (a - b)], vv);  // columns are sorted: b < a
+          else {
+            c.atomic_add_f64(&w.H[a * ldh + b], vv);
+            c.atomic_add_f64(&w.H[b * ldh + a], vv);
+          }
         }
       }
     }
@@ -581,7 +589,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         for (int i = c.tid(); i < p; i += NT) rhs[i] = w.act[i] ? -tc[i] : -w.dv[i];
         c.sync();
         CAVE_ACC(4);
-        c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
+        if constexpr (BAND) solve_spd_band(c, w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step);
+        else c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
         c.sync();
         CAVE_ACC(5);
         // ratio test to the first blocking bound
@@ -599,7 +608,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         if (blocked) {
           for (int i = c.tid(); i < p; i += NT) {
             double s = 0.0;
-            for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
+            if constexpr (BAND) {
+              const int j0 = i - w.bw > 0 ? i - w.bw : 0, j1 = i + w.bw < p - 1 ? i + w.bw : p - 1;
+              for (int j = j0; j <= j1; ++j) s += band_at(w.H, ldh, i, j) * w.step[j];
+            } else {
+              for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
+            }
             rhs[i] = s;  // rhs is dead until the next inner round
           }
           c.sync();
@@ -742,9 +756,23 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   return out;
 }
 
-template <class C>
+template <class C, bool BAND = false>
 CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
-  return v.pm1 ? solve_cone_impl<C, true>(c, v, w, max_iter, tol) : solve_cone_impl<C, false>(c, v, w, max_iter, tol);
+  return v.pm1 ? solve_cone_impl<C, true, BAND>(c, v, w, max_iter, tol)
+               : solve_cone_impl<C, false, BAND>(c, v, w, max_iter, tol);
+}
+
+// half bandwidth of M M^T in the reduced-row order: the widest span of reduced rows meeting in one
+// column (CSC columns are sorted by reduced-row index)
+template <class C>
+CAVE_HD int band_halfwidth(C& c, const SolveView& v) {
+  const uint32_t vmask = v.pm1 ? 0x7fffu : 0xffffu;
+  double bw = 0.0;
+  for (int k = c.tid(); k < v.d; k += C::NT) {
+    const uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
+    if (hi > lo + 1u) bw = fmax(bw, (double)((v.cvar[hi - 1] & vmask) - (v.cvar[lo] & vmask)));
+  }
+  return (int)c.reduce_max(bw);
 }
 
 // ------------------------------------------------------------------- epilogue

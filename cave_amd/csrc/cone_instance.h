@@ -76,20 +76,23 @@ CAVE_HD void fill_failure(C& c, int d, int64_t b, const OutPtrs& o) {
 }
 
 // scan the dense block + build the reduced cone; returns status
-template <class C>
+// (LARGE: the arena is global memory -> predicated scan stores, no dump slots)
+template <class C, bool LARGE = false>
 CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, int m, int d, uint32_t cap) {
   cb.d = d;
   cb.m = m;
-  if (m > 0xffff) return ST_TOO_LARGE;  // (row << 16) | col packing of the scan output
+  // (row << 16) | col packing of the scan output, 32-bit flat index
+  if (m > 0xffff || d > 0xffff || (uint64_t)m * (uint64_t)d > 0xffffffffull) return ST_TOO_LARGE;
   // scan output = build-phase temporaries at the top of the arena (+ per-thread dump slots)
-  cb.erc = ar.get_top<uint32_t>(cap + (uint32_t)C::NT);
-  cb.eall = ar.get_top<float>(cap + (uint32_t)C::NT);
+  const uint32_t dump_slots = LARGE ? 0u : (uint32_t)C::NT;
+  cb.erc = ar.get_top<uint32_t>(cap + dump_slots);
+  cb.eall = ar.get_top<float>(cap + dump_slots);
   cb.rptr = ar.get_top<uint32_t>((uint32_t)m + 1u);
   if (ar.ovf) return ST_TOO_LARGE;
   for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
   c.sync();
   CAVE_T0();
-  uint32_t nnz = c.scan_dense(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);  // erc = flat index for now
+  uint32_t nnz = c.template scan_dense<LARGE>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);  // erc = flat index for now
   c.sync();
   CAVE_ACC(10);
   if (nnz > cap) return ST_TOO_LARGE;
@@ -118,40 +121,81 @@ CAVE_HD SolveView view_of(const ConeBuild& cb) {
   return v;
 }
 
+// hot-first allocation of the large-cone path: LDS while it lasts, then the global workspace
+template <class T>
+CAVE_HD T* hot_get(Arena* hot, Arena& ar, uint32_t n) {
+  if (hot) {
+    T* q = hot->try_get<T>(n);
+    if (q) return q;
+  }
+  return ar.get<T>(n);
+}
+
 // Solve + epilogue for one instance whose SolveView is ready.  y must be loaded.
-template <class C>
-CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, float sign, float inner_ratio,
-                                 int max_iter, float* y, const float* avg, int64_t b, const OutPtrs& o,
-                                 int* iters_out) {
+// LARGE: band Hessian + solve_spd_band, work arrays hot-first (`hot` = LDS arena, `ar` = global workspace).
+template <class C, bool LARGE = false>
+CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v, int mode, float sign,
+                                 float inner_ratio, int max_iter, float* y, const float* avg, int64_t b,
+                                 const OutPtrs& o, int* iters_out) {
   const int d = v.d;
   const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER);
-  double* res = ar.get<double>(d);
-  double* tvec = ar.get<double>(d);
-  if (ar.ovf) return ST_TOO_LARGE;
   int32_t st = ST_OK;
   double f = 0.0;
   const bool empty = (v.n_valid == 0);
   *iters_out = 0;
+  double* res = nullptr;
+  double* tvec = nullptr;
+  if constexpr (!LARGE) {
+    res = ar.get<double>(d);
+    tvec = ar.get<double>(d);
+    if (ar.ovf) return ST_TOO_LARGE;
+  }
   if (need_proj && !empty) {
     const int p = v.p;
-    if (p > C::PMAX) return ST_TOO_LARGE;
+    const uint32_t pp = (uint32_t)(p > 0 ? p : 1);
     SolveWork w;
     w.y = y;
+    w.bw = 0; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr;
+    if constexpr (LARGE) {
+      const int bw = band_halfwidth(c, v);
+      const uint32_t ld = (uint32_t)bw + 1u;
+      if ((uint64_t)pp * ld > (1ull << 27)) return ST_TOO_LARGE;  // 1 GiB of band per instance
+      w.bw = bw;
+      w.ldh = (int)ld;
+      // small, touched every elimination step / every inner round: LDS first
+      w.bwin = hot_get<double>(hot, ar, ld * ld);
+      w.bz = hot_get<double>(hot, ar, pp);
+      w.step = hot_get<double>(hot, ar, pp);
+      w.g2 = hot_get<double>(hot, ar, pp);
+      w.act = hot_get<uint8_t>(hot, ar, pp);
+      w.ttry = hot_get<double>(hot, ar, pp);
+      w.dv = hot_get<double>(hot, ar, pp);
+      w.theta = hot_get<double>(hot, ar, pp);
+      w.g = hot_get<double>(hot, ar, pp);
+      w.rc = hot_get<double>(hot, ar, d);
+      res = hot_get<double>(hot, ar, d);
+      tvec = hot_get<double>(hot, ar, d);
+      w.dflag = hot_get<uint8_t>(hot, ar, d);
+      w.H = ar.get<double>(pp * ld);
+      w.bfac = ar.get<double>(pp * ld);
+    } else {
+      if (p > C::PMAX) return ST_TOO_LARGE;
+      w.rc = ar.get<double>(d);
+      w.dflag = ar.get<uint8_t>(d);
+      w.theta = ar.get<double>(pp);
+      w.ttry = ar.get<double>(pp);
+      w.g = ar.get<double>(pp);
+      w.dv = ar.get<double>(pp);
+      w.g2 = ar.get<double>(pp);
+      w.step = ar.get<double>(pp);
+      w.ldh = p | 1;
+      w.H = ar.get<double>((uint32_t)(p > 0 ? p * w.ldh : 1));
+      w.act = ar.get<uint8_t>(pp);
+    }
     w.res = res;
     w.q = tvec;  // the epilogue's target scratch is free while the solver runs
-    w.rc = ar.get<double>(d);
-    w.dflag = ar.get<uint8_t>(d);
-    w.theta = ar.get<double>(p > 0 ? p : 1);
-    w.ttry = ar.get<double>(p > 0 ? p : 1);
-    w.g = ar.get<double>(p > 0 ? p : 1);
-    w.dv = ar.get<double>(p > 0 ? p : 1);
-    w.g2 = ar.get<double>(p > 0 ? p : 1);
-    w.step = ar.get<double>(p > 0 ? p : 1);
-    w.ldh = p | 1;
-    w.H = ar.get<double>((uint32_t)(p > 0 ? p * w.ldh : 1));
-    w.act = ar.get<uint8_t>(p > 0 ? p : 1);
-    uint8_t* lflag = ar.get<uint8_t>(p > 0 ? p : 1);
-    uint32_t* llist = ar.get<uint32_t>(p > 0 ? p : 1);
+    uint8_t* lflag = ar.get<uint8_t>(pp);
+    uint32_t* llist = ar.get<uint32_t>(pp);
     if (ar.ovf) return ST_TOO_LARGE;
     for (int i = c.tid(); i < p; i += C::NT) lflag[i] = (uint8_t)((v.mptr[i + 1] - v.mptr[i]) > kLongRow ? 1 : 0);
     c.sync();
@@ -159,11 +203,15 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, 
     vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
     vv.longrow = llist;
     c.sync();
-    SolveResult r = solve_cone(c, vv, w, max_iter, 1e-10);
+    SolveResult r = solve_cone<C, LARGE>(c, vv, w, max_iter, 1e-10);
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
     if (st == ST_BAD_INPUT) return st;
+  } else if constexpr (LARGE) {
+    res = ar.get<double>(d);
+    tvec = ar.get<double>(d);
+    if (ar.ovf) return ST_TOO_LARGE;
   }
   EpilogueOut eo;
   eo.proj = o.proj ? o.proj + b * d : nullptr;
@@ -175,14 +223,18 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, const SolveView& v, int mode, 
   return st;
 }
 
-template <class C>
-CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P, int64_t b) {
+// LARGE: `ws` / `ws_bytes` is this workgroup's slice of the global workspace (the arena), LDS is the hot arena.
+template <class C, bool LARGE = false>
+CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P, int64_t b,
+                                unsigned char* ws = nullptr, uint32_t ws_bytes = 0) {
   const int d = P.d, m = P.m;
-  Arena ar;
-  ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
+  Arena ar, hot;
+  hot.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
+  if constexpr (LARGE) ar.init(ws, ws_bytes);
+  else ar = hot;
   ConeBuild cb;
   CAVE_T0();
-  int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
+  int32_t st = scan_and_build<C, LARGE>(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
   CAVE_ACC(0);
   int iters = 0;
   if (st == ST_OK) {
@@ -197,7 +249,8 @@ CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P,
       ar.release_top();  // build-phase temporaries (row tags, unit counts, pair scratch) are dead now
       SolveView v = view_of(cb);
       CAVE_ACC(1);
-      st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+      st = solve_and_finish<C, LARGE>(c, ar, LARGE ? &hot : nullptr, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y,
+                                      avg, b, P.o, &iters);
       CAVE_ACC(9);
     }
   }
@@ -208,14 +261,16 @@ CAVE_HD void run_dense_instance(C& c, unsigned char* smem, const DenseParams& P,
   }
 }
 
-template <class C>
-CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, int64_t b) {
+template <class C, bool LARGE = false>
+CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, int64_t b,
+                               unsigned char* ws = nullptr, uint32_t ws_bytes = 0) {
   const int d = P.d, m = P.m;
   const int NT = C::NT;
   Arena ar;
-  ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
+  if constexpr (LARGE) ar.init(ws, ws_bytes);
+  else ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
   ConeBuild cb;
-  int32_t st = scan_and_build(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
+  int32_t st = scan_and_build<C, LARGE>(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
   if (!P.fill) {
     if (c.tid() == 0) {
       P.n_rows[b] = (st == ST_OK) ? cb.p : 0;
@@ -324,7 +379,51 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
       v.mptr = mptr; v.mcol = mcol; v.mval = mval; v.vkind = vkind;
       v.cptr = cptr; v.cvar = cvar; v.cvalc = cvalc; v.usign = usign;
       v.nlong = 0; v.longrow = nullptr;
-      st = solve_and_finish(c, ar, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+      st = solve_and_finish(c, ar, nullptr, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+    }
+  }
+  if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);
+  if (c.tid() == 0) {
+    if (P.o.status) P.o.status[b] = st;
+    if (P.o.iters) P.o.iters[b] = iters;
+  }
+}
+
+// Large-cone form: the SolveView points straight into the store (global memory); only the row
+// pointers (the store keeps per-row extents) and the work arrays are carved from the workspace / LDS.
+template <class C>
+CAVE_HD void run_packed_large_instance(C& c, unsigned char* smem, const PackedParams& P, int64_t b, unsigned char* ws,
+                                       uint32_t ws_bytes) {
+  const cave_cone_store& S = P.store;
+  const int d = S.d;
+  const int NT = C::NT;
+  Arena ar, hot;
+  ar.init(ws, ws_bytes);
+  hot.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
+  const int64_t slot = P.ids ? P.ids[b] : b;
+  int32_t st = ST_OK;
+  int iters = 0;
+  if (slot < 0 || slot >= S.n) st = ST_BAD_INPUT;
+  else {
+    const int64_t r0 = S.row_off[slot], z0 = S.nnz_off[slot];
+    const int p = (int)(S.row_off[slot + 1] - r0);
+    const uint32_t nz = (uint32_t)(S.nnz_off[slot + 1] - z0);
+    const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
+    float* y = ar.get<float>(d);
+    uint32_t* mptr = ar.get<uint32_t>((uint32_t)p + 1u);
+    if (ar.ovf) st = ST_TOO_LARGE;
+    else {
+      for (int k = c.tid(); k < d; k += NT) y[k] = P.pred ? P.sign * P.pred[b * d + k] : 0.f;
+      for (int i = c.tid(); i < p; i += NT) mptr[i] = S.rlo[r0 + i];
+      if (c.tid() == 0) mptr[p] = nz;
+      c.sync();
+      SolveView v;
+      v.d = d; v.p = p; v.n_valid = S.n_valid[slot]; v.pm1 = false;
+      v.mptr = mptr; v.mcol = S.ccol + z0; v.mval = S.cval + z0; v.vkind = S.vkind + r0;
+      v.cptr = S.cptr + slot * (d + 1); v.cvar = S.cvar + z0; v.cvalc = S.cvalc + z0; v.usign = S.usign + slot * d;
+      v.nlong = 0; v.longrow = nullptr;
+      const float* avg = need_avg ? S.avg + slot * d : nullptr;
+      st = solve_and_finish<C, true>(c, ar, &hot, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
     }
   }
   if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);
@@ -387,6 +486,29 @@ static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& l
     lds = (int32_t)(need > kMaxLds ? kMaxLds : need);
   }
   return lds > 0 && (uint32_t)lds <= kMaxLds && cap > 0;
+}
+
+// ---- large-cone path: bytes of global workspace one workgroup needs (its arena).
+// `band` = p * (bw + 1) entries of the band Hessian (kept twice: H and its factor).
+static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int64_t band) {
+  const int64_t rows_raw = m, p = m < 65534 ? m : 65534, nnzM = cap;
+  uint64_t persist = align8u(d) + align8u(4 * (d + 1)) + align8u(4 * (p + 1)) + align8u(p) + 2 * align8u(2 * nnzM) +
+                     2 * align8u(4 * nnzM);
+  uint64_t scan = 2 * (uint64_t)align8u(4 * cap) + align8u(4 * (m + 1));
+  uint64_t temps = align8u(4 * d) + align8u(4 * m) + align8u(m) + align8u(4 * (cap / 64 + 1)) + 3 * align8u(4 * rows_raw) +
+                   align8u(rows_raw) + align8u(2 * m) +
+                   (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d)) + align8u(4 * p);
+  uint64_t vecs = 2 * align8u(4 * d);
+  uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) + align8u(4 * p) +
+                   3 * (uint64_t)8 * (uint64_t)(band + 1);  // H, factor, ring window ((bw+1)^2 <= p*(bw+1))
+  uint64_t build_peak = persist + scan + temps + vecs;
+  uint64_t solve_peak = persist + vecs + solve;
+  return (build_peak > solve_peak ? build_peak : solve_peak) + 256;
+}
+static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band) {
+  const int64_t p = max_rows > 0 ? max_rows : 1;
+  return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) +
+         align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 256;
 }
 
 static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false) {

@@ -26,6 +26,8 @@ struct BlockCtx {
     uint32_t u32[2][8];
   };
   static constexpr uint32_t SCRATCH_BYTES = 256;
+  static constexpr int NWAVES = NW;
+  static constexpr int WL = 64;
   static_assert(sizeof(Scratch) <= SCRATCH_BYTES && NW <= 8, "scratch layout");
   int lane, wave, t;
   uint32_t par;
@@ -41,6 +43,11 @@ struct BlockCtx {
     sc = reinterpret_cast<Scratch*>(smem);
   }
   __device__ __forceinline__ int tid() const { return t; }
+  __device__ __forceinline__ int wave_id() const { return wave; }
+  __device__ __forceinline__ int lane_id() const { return lane; }
+  // sum / max over the lanes of the calling wave only (no barrier; every lane gets the result)
+  __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
+  __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
 
   __device__ __forceinline__ double reduce_sum(double v) {
@@ -146,6 +153,7 @@ struct BlockCtx {
   // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns
   // the U consecutive 1 KiB chunks [w*U, (w+1)*U) of a NW*U KiB window, so flat order is
   // wave-major; one barrier per round turns the per-wave non-zero counts into slot bases.
+  template <bool COND = false>
   __device__ __forceinline__ uint32_t scan_dense(const float* __restrict__ A, uint32_t n, uint32_t* eflat, float* eval,
                                                  uint32_t cap) {
     constexpr int U = SCAN_UNROLL;
@@ -186,7 +194,8 @@ struct BlockCtx {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           uint32_t i = r0 + woff + (uint32_t)u * 64u;
-          chunk_emit(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, dump, eflat, eval, cap);
+          if constexpr (COND) chunk_emit_cond(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, eflat, eval, cap);
+          else chunk_emit(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, dump, eflat, eval, cap);
         }
       }
       cursor += tot;

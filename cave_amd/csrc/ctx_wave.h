@@ -16,12 +16,19 @@ struct WaveCtx {
   static constexpr int PMAX = 64;        // largest reduced system solve_spd holds in registers
   static constexpr int KREG = 4;         // line search keeps r, q in registers when d <= KREG * NT
   static constexpr uint32_t SCRATCH_BYTES = 0;
+  static constexpr int NWAVES = 1;       // waves per instance
+  static constexpr int WL = 64;          // lanes per wave
   int lane;
 #ifdef CAVE_STAMPS
   unsigned long long st[16];
 #endif
   __device__ __forceinline__ void init(unsigned char*) { lane = (int)threadIdx.x; }
   __device__ __forceinline__ int tid() const { return lane; }
+  __device__ __forceinline__ int wave_id() const { return 0; }
+  __device__ __forceinline__ int lane_id() const { return lane; }
+  // sum / max over the lanes of the calling wave only (no barrier; every lane gets the result)
+  __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
+  __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ double reduce_sum(double v) const { return wave_sum_f64(v); }
   __device__ __forceinline__ void reduce_sum2(double& a, double& b) const { a = wave_sum_f64(a); b = wave_sum_f64(b); }
@@ -83,6 +90,8 @@ struct WaveCtx {
   // (entries beyond `cap` are counted, not stored; eflat/eval need cap + NT slots, the last NT are
   // per-thread dump slots).  Row/column are derived afterwards, once per entry
   // (cone_instance.h scan_and_build), so the per-KiB loop stays short.
+  // COND = true: eflat / eval live in global memory -> predicated stores instead of dump slots.
+  template <bool COND = false>
   __device__ __forceinline__ uint32_t scan_dense(const float* __restrict__ A, uint32_t n, uint32_t* eflat, float* eval,
                                                  uint32_t cap) const {
     constexpr int U = SCAN_UNROLL;
@@ -116,7 +125,8 @@ struct WaveCtx {
         if (i >= n4) v = z4;
         ChunkSlots s = chunk_slots(v);
         if (s.total == 0u) continue;  // wave-uniform
-        chunk_emit(v, head + 4u * i, cursor, s.rel, s.nzm, dump, eflat, eval, cap);
+        if constexpr (COND) chunk_emit_cond(v, head + 4u * i, cursor, s.rel, s.nzm, eflat, eval, cap);
+        else chunk_emit(v, head + 4u * i, cursor, s.rel, s.nzm, dump, eflat, eval, cap);
         cursor += s.total;
       }
     };

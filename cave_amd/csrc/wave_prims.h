@@ -171,4 +171,16 @@ __device__ __forceinline__ void chunk_emit(float4 v, uint32_t f, uint32_t base, 
   eflat[i3] = f + 3u; eval[i3] = v.w;
 }
 
+// Variant for output arrays in global memory (large-cone path): predicated stores, no dump slots
+// (a store per zero element would double the HBM traffic of the scan).
+__device__ __forceinline__ void chunk_emit_cond(float4 v, uint32_t f, uint32_t base, uint32_t rel, uint32_t nzm,
+                                                uint32_t* eflat, float* eval, uint32_t cap) {
+  const uint32_t p0 = base + rel;
+  const uint32_t p1 = p0 + (nzm & 1u), p2 = p1 + ((nzm >> 1) & 1u), p3 = p2 + ((nzm >> 2) & 1u);
+  if ((nzm & 1u) && p0 < cap) { eflat[p0] = f;      eval[p0] = v.x; }
+  if ((nzm & 2u) && p1 < cap) { eflat[p1] = f + 1u; eval[p1] = v.y; }
+  if ((nzm & 4u) && p2 < cap) { eflat[p2] = f + 2u; eval[p2] = v.z; }
+  if ((nzm & 8u) && p3 < cap) { eflat[p3] = f + 3u; eval[p3] = v.w; }
+}
+
 }  // namespace cave

@@ -21,7 +21,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .qpsolver import _grow_limits, _raise_for_status
+from .qpsolver import _grow_limits, _large_guess, _raise_for_status, fast_path_cannot_fit
 
 __all__ = ["ConeStore", "PackedBatch", "collate_ids"]
 
@@ -58,8 +58,18 @@ class ConeStore:
         d = int(chunks[0].shape[2])
         self = cls(d, dev)
         stream = _lib.current_stream()
-        # pass 1: counts (default launch limits are sized for small structured cones; a chunk that
-        # does not fit is re-counted with one wave per instance and the full 160 KiB arena)
+        # pass 1: counts.  Default launch limits are sized for small structured cones; a chunk that does
+        # not fit is re-counted with one wave per instance and the full 160 KiB arena, then on the
+        # large-cone path (global workspace).  lim = (nnz_cap, lds_bytes, waves) or ("large", nnz_cap).
+        def pack_large(x, cap, n_rows, n_nnz, store, slot, status):
+            B, m, _ = x.shape
+            slice_bytes = int(lib.cave_hip_large_slice_bytes(m, d, cap, 1))
+            slots = _lib.large_slots(dev, B, slice_bytes)
+            ws = _lib.workspace(dev, slots * slice_bytes)
+            _lib.check(lib.cave_hip_pack_large(_lib.ptr(x), B, m, d, cap, _lib.ptr(ws), slice_bytes, slots,
+                                               _lib.ptr(n_rows), _lib.ptr(n_nnz), store, slot, _lib.ptr(status), stream),
+                       "cave_hip_pack_large")
+
         counts, limits = [], []
         for ch in chunks:
             x = ch.to(device=dev, dtype=torch.float32).contiguous()
@@ -68,13 +78,25 @@ class ConeStore:
             n_nnz = torch.empty(B, dtype=torch.int32, device=dev)
             status = torch.empty(B, dtype=torch.int32, device=dev)
             lim = (0, 0, 0)
-            for attempt in range(2):
-                _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, lim[0], lim[1], lim[2], _lib.ptr(n_rows),
-                                                   _lib.ptr(n_nnz), _lib.ptr(status), stream), "cave_hip_pack_count")
-                if attempt == 0 and bool((status == _lib.ST_TOO_LARGE).any()):
-                    cap, lds = _grow_limits(m, d)
-                    lim = (cap, lds, 1)
-                    continue
+            tier = 2 if fast_path_cannot_fit(d) else 0
+            while True:
+                if tier < 2:
+                    _lib.check(lib.cave_hip_pack_count(_lib.ptr(x), B, m, d, lim[0], lim[1], lim[2], _lib.ptr(n_rows),
+                                                       _lib.ptr(n_nnz), _lib.ptr(status), stream), "cave_hip_pack_count")
+                    if bool((status == _lib.ST_TOO_LARGE).any()):
+                        tier += 1
+                        if tier == 1:
+                            cap, lds = _grow_limits(m, d)
+                            lim = (cap, lds, 1)
+                        continue
+                    break
+                cap = _large_guess(m, d)[0]
+                for attempt in range(5):
+                    pack_large(x, cap, n_rows, n_nnz, None, 0, status)
+                    if not bool((status == _lib.ST_TOO_LARGE).any()):
+                        break
+                    cap = min(2 * cap, max(m * d, 64))
+                lim = ("large", cap)
                 break
             _raise_for_status(status, "ConeStore pack")
             counts.append((n_rows, n_nnz))
@@ -110,17 +132,39 @@ class ConeStore:
             x = ch.to(device=dev, dtype=torch.float32).contiguous()
             B, m, _ = x.shape
             status = torch.empty(B, dtype=torch.int32, device=dev)
-            _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, lim[0], lim[1], lim[2], C.byref(self._c), slot,
-                                              _lib.ptr(status), stream), "cave_hip_pack_fill")
+            if lim[0] == "large":
+                pack_large(x, lim[1], None, None, C.byref(self._c), slot, status)
+            else:
+                _lib.check(lib.cave_hip_pack_fill(_lib.ptr(x), B, m, d, lim[0], lim[1], lim[2], C.byref(self._c), slot,
+                                                  _lib.ptr(status), stream), "cave_hip_pack_fill")
             _raise_for_status(status, "ConeStore fill")
             slot += B
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
         self.waves = 0  # 0 = choose per call
         self.all_pm1 = bool((t["flags"] & 1).all()) if N else False
         self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, int(self.all_pm1)))
-        if self.lds_bytes <= 0:
-            raise RuntimeError("ConeStore: largest instance does not fit a 160 KiB LDS arena")
+        # cones beyond the LDS-resident solver (more than 64 reduced rows or too many non-zeros) run on the
+        # large-cone path, which reads the store in place and keeps the Newton systems as bands
+        self.large = self.lds_bytes <= 0 or self.max_rows > 64
+        self.band_entries = self._max_band_entries() if self.large else 0
         return self
+
+    def _max_band_entries(self) -> int:
+        """max over instances of rows * (half bandwidth + 1) of M M^T in the stored row order
+        (half bandwidth = widest span of reduced-row indices meeting in one column of the CSC)."""
+        t, d, N = self.t, self.d, self.n
+        if N == 0 or self.max_nnz == 0:
+            return 1
+        cptr = t["cptr"].view(N, d + 1).to(torch.int64)
+        base = t["nnz_off"][:-1, None]
+        lo, hi = cptr[:, :-1] + base, cptr[:, 1:] + base
+        cvar = t["cvar"].to(torch.int64) & 0xffff
+        last = cvar[(hi - 1).clamp_(min=0)]
+        first = cvar[lo.clamp_(max=cvar.numel() - 1)]
+        span = torch.where(hi > lo, last - first, torch.zeros_like(lo))
+        bw = span.max(dim=1).values
+        rows = t["row_off"][1:] - t["row_off"][:-1]
+        return int((rows * (bw + 1)).max().item())
 
     # -------------------------------------------------------------------- use
     def _waves_for(self, B: int) -> int:
@@ -160,13 +204,25 @@ class ConeStore:
             out["status"], out["iters"] = status, iters
             if B == 0:
                 return out
-            rc = lib.cave_hip_cone_packed(
-                C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                int(max_iter), self.lds_bytes, self._waves_for(B),
-                _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
-                _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
-                _lib.current_stream())
-            _lib.check(rc, "cave_hip_cone_packed")
+            if self.large:
+                slice_bytes = int(lib.cave_hip_packed_large_slice_bytes(d, self.max_rows, self.band_entries))
+                slots = _lib.large_slots(dev, B, slice_bytes)
+                ws = _lib.workspace(dev, slots * slice_bytes)
+                rc = lib.cave_hip_cone_packed_large(
+                    C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
+                    int(max_iter), 0, _lib.ptr(ws), slice_bytes, slots,
+                    _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
+                    _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+                    _lib.current_stream())
+                _lib.check(rc, "cave_hip_cone_packed_large")
+            else:
+                rc = lib.cave_hip_cone_packed(
+                    C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
+                    int(max_iter), self.lds_bytes, self._waves_for(B),
+                    _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
+                    _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+                    _lib.current_stream())
+                _lib.check(rc, "cave_hip_cone_packed")
             if check:
                 _raise_for_status(status, "solver='hip' (packed)")
         return out

@@ -40,8 +40,24 @@ def _grow_limits(m: int, d: int) -> tuple[int, int]:
 
 
 # shapes (m_max, d) whose cones did not fit the default (structured-cone) arena: go straight to the
-# large limits next time instead of paying a failed launch per call
-_needs_large: set[tuple[int, int]] = set()
+# tier that worked next time instead of paying failed launches per call
+#   tier 1: one wave per instance, full 160 KiB LDS arena;  tier 2: large-cone path (global workspace)
+_tier: dict[tuple[int, int], int] = {}
+_large_hint: dict[tuple[int, int], tuple[int, int]] = {}  # (m, d) -> (nnz_cap, band_entries) that fitted
+
+
+def _large_guess(m: int, d: int) -> tuple[int, int]:
+    """Initial (nnz_cap, band_entries) of the large-cone path: structured cones carry <= d unit entries
+    plus a few sparse rows; the reduced systems of the CaVE benchmarks are ~sqrt(2d) dense rows (TSP
+    degree rows) or ~d/2 rows of bandwidth ~sqrt(d/2) (grid flow rows): both well under 32*d entries."""
+    cap = int(min(max(m * d, 64), 4 * (m + d) + 256))
+    return cap, 32 * d + 4096
+
+
+def fast_path_cannot_fit(d: int) -> bool:
+    """The per-coordinate arrays of the LDS-resident solver (sign byte, column pointers, y, avg,
+    residual, clipped residual, direction, flags: ~38 bytes per cost coordinate) alone exceed 160 KiB."""
+    return 38 * d + 4096 > _lib.MAX_LDS
 
 
 def _raise_for_status(status: torch.Tensor, what: str) -> None:
@@ -55,8 +71,8 @@ def _raise_for_status(status: torch.Tensor, what: str) -> None:
         raise HipSolverError(f"{what}: Maximum number of iterations reached ({bad} instance(s), first index {first}).")
     if code == ST_TOO_LARGE:
         raise HipSolverError(
-            f"{what}: {bad} cone(s) (first index {first}) do not fit one workgroup's 160 KiB LDS arena "
-            "(more than 64 reduced rows, or too many non-zeros); larger cones are not supported by this build.")
+            f"{what}: {bad} cone(s) (first index {first}) did not fit the workspace of the large-cone path "
+            "after 4 size doublings (non-zeros / band of the reduced system).")
     if code == ST_BAD_INPUT:
         raise ValueError(f"{what}: non-finite input in {bad} instance(s), first index {first}.")
     raise HipSolverError(f"{what}: unknown status {code}")
@@ -72,8 +88,9 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
     ``waves``: wavefronts cooperating per instance (0 = library default 2; 1 or 2: reduced systems
     up to 64 rows; 4: up to 32 rows).
     With ``check=True`` (default) the per-instance status is read back (one host sync):
-    a cone that does not fit is retried once with one wave per instance and the largest
-    arena, anything else raises.
+    a batch with a cone that does not fit is retried with one wave per instance and the largest
+    LDS arena, then on the large-cone path (global workspace, band Newton systems: TSP-100,
+    30x30 grids); the tier that worked is remembered per (m_max, d).  Anything else raises.
     """
     lib = _lib.load()
     if tight_ctrs.dim() != 3:
@@ -109,17 +126,52 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
                 _lib.current_stream())
             _lib.check(rc, "cave_hip_cone_dense")
 
+        def launch_large(cap: int, band: int) -> None:
+            slice_bytes = int(lib.cave_hip_large_slice_bytes(m, d, cap, band))
+            if slice_bytes <= 0 or slice_bytes >= 1 << 32:
+                raise HipSolverError(f"solver='hip': a cone of this size needs a {slice_bytes}-byte workspace slice "
+                                     "(limit 4 GiB)")
+            slots = _lib.large_slots(dev, B, slice_bytes)
+            ws = _lib.workspace(dev, slots * slice_bytes)
+            rc = lib.cave_hip_cone_dense_large(
+                _lib.ptr(ctrs), _lib.ptr(pred), B, m, d, int(mode), float(sign), float(inner_ratio),
+                int(max_iter), int(cap), 0, _lib.ptr(ws), slice_bytes, slots,
+                _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
+                _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+                _lib.current_stream())
+            _lib.check(rc, "cave_hip_cone_dense_large")
+
+        def run_large() -> None:
+            cap, band = _large_hint.get((m, d), _large_guess(m, d))
+            cap = max(cap, nnz_cap)
+            for attempt in range(5):
+                launch_large(cap, band)
+                if not check or not bool((status == ST_TOO_LARGE).any()):
+                    break
+                cap, band = min(2 * cap, max(m * d, 64)), 4 * band
+            _large_hint[(m, d)] = (cap, band)
+
         auto = lds_bytes == 0
-        if auto and (m, d) in _needs_large:
+        if auto and (m, d) not in _tier and fast_path_cannot_fit(d):
+            _tier[(m, d)] = 2
+        tier = _tier.get((m, d), 0) if auto else 0
+        if m > 65535:
+            raise HipSolverError("solver='hip': more than 65535 rows per instance are not supported")
+        if tier == 2:
+            run_large()
+        elif tier == 1:
             cap, lds = _grow_limits(m, d)
             launch(max(cap, nnz_cap), lds, 1)
         else:
             launch(nnz_cap, lds_bytes, waves)
         if check:
-            if bool((status == ST_TOO_LARGE).any()) and auto and (m, d) not in _needs_large:
-                _needs_large.add((m, d))
+            if auto and tier == 0 and bool((status == ST_TOO_LARGE).any()):
+                tier = _tier[(m, d)] = 1
                 cap, lds = _grow_limits(m, d)
                 launch(max(cap, nnz_cap), lds, 1)
+            if auto and tier == 1 and bool((status == ST_TOO_LARGE).any()):
+                tier = _tier[(m, d)] = 2
+                run_large()
             _raise_for_status(status, "solver='hip'")
     return out
 

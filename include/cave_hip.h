@@ -22,6 +22,10 @@
  *   cave_hip_pack_*  / cave_hip_cone_packed
  *                                       optDatasetConstrs.ctrs storage + collate_fn padding
  *                                       src/dataset.py:72, 133-144 (device-resident replacement)
+ *   cave_hip_*_large                    the same three operators for cones whose reduced system does
+ *                                       not fit registers / LDS (TSP-100, 30x30 shortest path: the
+ *                                       reference runs them through the same _project_nnls,
+ *                                       src/cave.py:298-309); caller-owned global workspace
  */
 #ifndef CAVE_HIP_H
 #define CAVE_HIP_H
@@ -33,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 4
+#define CAVE_HIP_ABI_VERSION 5
 
 /* return codes */
 #define CAVE_OK 0
@@ -147,6 +151,39 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
  * (max_rows / max_nnz over instances, from the pass-1 counts).  all_pm1 != 0: every instance has
  * flags bit0 set, so no value arrays are staged (smaller arena -> more workgroups per CU). */
 int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1);
+
+/* ------------------------------------------------------------------ large-cone path
+ * Same operators, same per-instance semantics and outputs, for cones beyond the fast path's limits
+ * (more than 64 reduced rows, or more non-zeros than 160 KiB of LDS holds).  Persistent 4-wave
+ * workgroups; each works in its own slice of a caller-owned, 16-byte aligned device `workspace` of
+ * n_slots * slice_bytes bytes (n_slots = number of workgroups launched, at most B are used; a few per
+ * CU is enough).  The Newton systems are kept as symmetric bands (band = reduced rows x (half
+ * bandwidth + 1) entries) and solved by an LDL^T band elimination.  An instance that does not fit its
+ * slice reports CAVE_ST_TOO_LARGE: retry with a larger slice.
+ *   nnz_cap       non-zeros kept per instance
+ *   band_entries  expected rows x (bandwidth + 1) of the reduced system (sizing hint)
+ *   lds_bytes     LDS per workgroup used for the small hot arrays, 0 = 64 KiB */
+int64_t cave_hip_large_slice_bytes(int64_t m_max, int64_t d, int64_t nnz_cap, int64_t band_entries);
+int64_t cave_hip_packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band_entries);
+
+int32_t cave_hip_cone_dense_large(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d,
+                                  int32_t mode, float sign, float inner_ratio, int32_t max_iter, int64_t nnz_cap,
+                                  int32_t lds_bytes, void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj,
+                                  float* rnorm, float* target, float* loss, float* grad, int32_t* status,
+                                  int32_t* iters, void* stream);
+
+/* store == NULL: count pass (n_rows / n_nnz per instance, as cave_hip_pack_count);
+ * store != NULL: fill pass into slots [slot0, slot0 + B) (as cave_hip_pack_fill; n_rows / n_nnz unused). */
+int32_t cave_hip_pack_large(const float* ctrs, int64_t B, int64_t m_max, int64_t d, int64_t nnz_cap, void* workspace,
+                            int64_t slice_bytes, int32_t n_slots, int32_t* n_rows, int32_t* n_nnz,
+                            const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream);
+
+/* reads the cones in place from the store; the workspace only holds the solver's work arrays */
+int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
+                                   int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
+                                   void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj, float* rnorm,
+                                   float* target, float* loss, float* grad, int32_t* status, int32_t* iters,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,13 @@ struct SerialCtx {
   void reduce_sum2(double&, double&) const {}
   double team_reduce_sum(double v) const { return v; }
   static constexpr int PMAX = 64;
+  static constexpr int NWAVES = 1;
+  static constexpr int WL = 1;
   int tid() const { return 0; }
+  int wave_id() const { return 0; }
+  int lane_id() const { return 0; }
+  double wave_sum(double v) const { return v; }
+  double wave_max(double v) const { return v; }
   void sync() const {}
   double reduce_sum(double v) const { return v; }
   double reduce_max(double v) const { return v; }
@@ -40,6 +46,7 @@ struct SerialCtx {
     for (int i = 0; i < n; ++i) if (f[i]) out[c++] = (uint32_t)i;
     return c;
   }
+  template <bool COND = false>
   uint32_t scan_dense(const float* A, uint32_t n, uint32_t* eflat, float* eval, uint32_t cap) const {
     uint32_t cur = 0;
     for (uint32_t f = 0; f < n; ++f) {

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "emul", "emul_abi.cpp")
 _DEPS = [
     _SRC,
+    os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_band.h"),
     os.path.join(_HERE, "emul", "ctx_serial.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_core.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_common.h"),
@@ -114,6 +115,80 @@ class Emul:
         rc = self.lib.cave_emul_cone_packed(
             C.byref(store), _p(ids), _p(pred), C.c_int64(B), C.c_int32(mode), C.c_float(sign),
             C.c_float(inner_ratio), C.c_int32(max_iter), C.c_int32(lds),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
+
+    # ---- large-cone path (global-workspace arena, band Newton systems)
+    def _outs(self, B, d):
+        return {
+            "proj": np.zeros((B, d), np.float32), "rnorm": np.zeros(B, np.float32),
+            "target": np.zeros((B, d), np.float32), "loss": np.zeros(B, np.float32),
+            "grad": np.zeros((B, d), np.float32), "status": np.zeros(B, np.int32),
+            "iters": np.zeros(B, np.int32),
+        }
+
+    def large_slice_bytes(self, m, d, nnz_cap, band):
+        self.lib.cave_emul_large_slice_bytes.restype = C.c_int64
+        return int(self.lib.cave_emul_large_slice_bytes(C.c_int64(m), C.c_int64(d), C.c_int64(nnz_cap), C.c_int64(band)))
+
+    def cone_dense_large(self, ctrs, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0, nnz_cap=0, band=0,
+                         lds_bytes=64 * 1024, slice_bytes=0):
+        ctrs = np.ascontiguousarray(ctrs, dtype=np.float32)
+        B, m, d = ctrs.shape
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        nnz_cap = nnz_cap or max(64, int((ctrs != 0).reshape(B, -1).sum(1).max(initial=0)))
+        band = band or 32 * d + 4096
+        slice_bytes = slice_bytes or self.large_slice_bytes(m, d, nnz_cap, band)
+        out = self._outs(B, d)
+        rc = self.lib.cave_emul_cone_dense_large(
+            _p(ctrs), _p(pred), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int32(mode), C.c_float(sign),
+            C.c_float(inner_ratio), C.c_int32(max_iter), C.c_int64(nnz_cap), C.c_int32(lds_bytes), C.c_int64(slice_bytes),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
+
+    def pack_large(self, ctrs, nnz_cap=0, band=0):
+        ctrs = np.ascontiguousarray(ctrs, dtype=np.float32)
+        B, m, d = ctrs.shape
+        nnz_cap = nnz_cap or max(64, int((ctrs != 0).reshape(B, -1).sum(1).max(initial=0)))
+        slice_bytes = self.large_slice_bytes(m, d, nnz_cap, band or 1)
+        n_rows = np.zeros(B, np.int32); n_nnz = np.zeros(B, np.int32); status = np.zeros(B, np.int32)
+        rc = self.lib.cave_emul_pack_large(_p(ctrs), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int64(nnz_cap),
+                                           C.c_int64(slice_bytes), _p(n_rows), _p(n_nnz), None, C.c_int64(0), _p(status))
+        assert rc == 0 and (status == 0).all(), (rc, status)
+        row_off = np.concatenate([[0], np.cumsum(n_rows, dtype=np.int64)]).astype(np.int64)
+        nnz_off = np.concatenate([[0], np.cumsum(n_nnz, dtype=np.int64)]).astype(np.int64)
+        R, Z = int(row_off[-1]), int(nnz_off[-1])
+        arrs = {
+            "row_off": row_off, "nnz_off": nnz_off, "n_valid": np.zeros(B, np.int32), "flags": np.zeros(B, np.uint8),
+            "usign": np.zeros(B * d, np.uint8), "avg": np.zeros(B * d, np.float32),
+            "vkind": np.zeros(max(R, 1), np.uint8), "rlo": np.zeros(max(R, 1), np.uint32),
+            "rhi": np.zeros(max(R, 1), np.uint32), "ccol": np.zeros(max(Z, 1), np.uint16),
+            "cval": np.zeros(max(Z, 1), np.float32), "cptr": np.zeros(B * (d + 1), np.uint32),
+            "cvar": np.zeros(max(Z, 1), np.uint16), "cvalc": np.zeros(max(Z, 1), np.float32),
+        }
+        st = Store(n=B, d=d, reserved=0, **{k: v.ctypes.data for k, v in arrs.items()})
+        rc = self.lib.cave_emul_pack_large(_p(ctrs), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int64(nnz_cap),
+                                           C.c_int64(slice_bytes), None, None, C.byref(st), C.c_int64(0), _p(status))
+        assert rc == 0 and (status == 0).all(), (rc, status)
+        return st, arrs, int(n_rows.max(initial=0)), int(n_nnz.max(initial=0))
+
+    def cone_packed_large(self, store, arrs, max_rows, ids, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0,
+                          band=0, lds_bytes=64 * 1024):
+        d = store.d
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        B = len(ids)
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        self.lib.cave_emul_packed_large_slice_bytes.restype = C.c_int64
+        band = band or max_rows * max_rows
+        slice_bytes = int(self.lib.cave_emul_packed_large_slice_bytes(C.c_int64(d), C.c_int64(max_rows), C.c_int64(band)))
+        out = self._outs(B, d)
+        rc = self.lib.cave_emul_cone_packed_large(
+            C.byref(store), _p(ids), _p(pred), C.c_int64(B), C.c_int32(mode), C.c_float(sign), C.c_float(inner_ratio),
+            C.c_int32(max_iter), C.c_int32(lds_bytes), C.c_int64(slice_bytes),
             _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
             _p(out["status"]), _p(out["iters"]))
         assert rc == 0, rc
