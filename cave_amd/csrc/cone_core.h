@@ -502,9 +502,14 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   double* r = w.res;    // UNCLIPPED residual y - M^T theta during the iteration
   double* rc = w.rc;    // its clipped image Pi(r)
   for (int i = c.tid(); i < p; i += NT) theta[i] = 0.0;
-  double yy = 0.0;
-  for (int k = c.tid(); k < d; k += NT) { yy += (double)w.y[k] * (double)w.y[k]; r[k] = (double)w.y[k]; }
+  double yy = 0.0, ymax = 0.0;
+  for (int k = c.tid(); k < d; k += NT) {
+    yy += (double)w.y[k] * (double)w.y[k];
+    r[k] = (double)w.y[k];
+    if constexpr (BAND) ymax = fmax(ymax, fabs((double)w.y[k]));
+  }
   yy = c.reduce_sum(yy);
+  if constexpr (BAND) ymax = c.reduce_max(ymax);
   c.sync();
   double f = refresh_clipped(c, v, r, rc);
   const int ldh = w.ldh;
@@ -535,6 +540,48 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // (src/cave.py:218) needs rnorm itself resolved, so the gradient test is tightened.
     const double tol_it = (f < 1e-8 * yy) ? 1e-4 * tol : tol;
     if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy) { converged = true; break; }
+    if constexpr (BAND) {
+      // Large-cone path: SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
+      // the CHKS smoothing of the one-sided clip at scale mu (1/2 at the kink, -> the 0/1 activity D_kk
+      // as mu -> 0); mu shrinks tenfold per iteration from 0.1*max|y| but stays above 0.03*max|y| times
+      // the relative projected gradient, so it vanishes with the error (superlinear end game) while
+      // coordinates resting exactly on their kink keep weight 1/2 instead of flipping every iteration.
+      // Coordinates about to switch on thus resist the step before they do: with the binary D the
+      // active set of a grid shortest-path cone grows one graph layer per iteration (60-100
+      // iterations on a 30x30 grid), with W it takes 7-10.  The gradient and the line search stay exact,
+      // so every step still decreases f and the limit is the same projection.  H is rebuilt per
+      // iteration (O(sum of squared column counts) atomics).
+      for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+      c.sync();
+      double mu = (it < 6) ? 0.1 * ymax * pow(0.1, (double)it) : 0.0;
+      mu = fmax(mu, 0.03 * ymax * (pgn / g0n));
+      for (int k = c.tid(); k < d; k += NT) {
+        const uint8_t u = v.usign[k];
+        double wk;
+        if (u == 0) wk = 1.0;
+        else if (u == 3) wk = 0.0;
+        else {
+          const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
+          if (mu > 0.0) {
+            const double z = t / mu;
+            wk = 0.5 * (1.0 + z / sqrt(1.0 + z * z));
+          } else wk = (t > 0.0) ? 1.0 : 0.0;
+        }
+        if (!(wk > 1e-14)) continue;
+        uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
+        for (uint32_t e1 = lo; e1 < hi; ++e1) {
+          uint32_t a, b;
+          double v1, v2;
+          csc_entry<PM1>(v, e1, a, v1);
+          const double va = wk * v1;
+          c.atomic_add_f64(&w.H[a * ldh], va * v1);
+          for (uint32_t e2 = lo; e2 < e1; ++e2) {
+            csc_entry<PM1>(v, e2, b, v2);
+            c.atomic_add_f64(&w.H[b * ldh + (a - b)], va * v2);  // columns are sorted: b < a
+          }
+        }
+      }
+    } else {
     // generalised Hessian H = M D M^T, D = [Pi(r) != 0]: rank-one updates +-m_k m_k^T for the
     // coordinates whose activity flipped since the previous iteration (all active ones at it 0)
     for (int k = c.tid(); k < d; k += NT) {
@@ -548,18 +595,15 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         double v1, v2;
         csc_entry<PM1>(v, e1, a, v1);
         const double va = sg * v1;
-        if constexpr (BAND) c.atomic_add_f64(&w.H[a * ldh], va * v1);
-        else c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
+        c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
         for (uint32_t e2 = lo; e2 < e1; ++e2) {
           csc_entry<PM1>(v, e2, b, v2);
           double vv = va * v2;
-          if constexpr (BAND) c.atomic_add_f64(&w.H[b * ldh + (a - b)], vv);  // columns are sorted: b < a
-          else {
-            c.atomic_add_f64(&w.H[a * ldh + b], vv);
-            c.atomic_add_f64(&w.H[b * ldh + a], vv);
-          }
+          c.atomic_add_f64(&w.H[a * ldh + b], vv);
+          c.atomic_add_f64(&w.H[b * ldh + a], vv);
         }
       }
+    }
     }
     c.sync();
     CAVE_ACC(3);
