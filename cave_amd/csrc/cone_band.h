@@ -54,11 +54,25 @@ CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, c
     }
     z[i] = zi;
   }
+  if (bw == 0) {  // diagonal system
+    for (int i = c.tid(); i < p; i += NT) {
+      const double dk = act[i] ? 1.0 : Hb[i] + reg;
+      x[i] = (dk > 1e-300) ? z[i] / dk : 0.0;
+    }
+    c.sync();
+    return;
+  }
   // ring window: band row r lives in slot r % ld
   for (int idx = c.tid(); idx < ld * ld; idx += NT) {
     const int r = idx / ld, t = idx - r * ld;
     win[idx] = band_row_entry(Hb, ld, act, p, reg, r, t);
   }
+  // One barrier per pivot.  Step k: (A) pivot k updates rows k+1 .. k+bw-1 of the window and z;
+  // (B) row k-1, final since the previous barrier, is retired to the factor and its slot takes row
+  // k+bw of H -- the one row pivot k reaches only in its diagonal entry, which the inserting thread
+  // adjusts itself.  A and B touch disjoint slots.  The H row for step k+1 is loaded one step ahead.
+  double pre = (c.tid() <= bw) ? band_row_entry(Hb, ld, act, p, reg, ld, c.tid()) : 0.0;  // row 0 + ld, for step 1
+  double inv_prev = 0.0;
   c.sync();
   for (int k = 0; k < p; ++k) {
     double* wk = win + (k % ld) * ld;
@@ -66,33 +80,72 @@ CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, c
     const bool ok = dk > 1e-300;
     const double inv = ok ? 1.0 / dk : 0.0;
     const int nb = bw < p - 1 - k ? bw : p - 1 - k;
+    // rows updated by phase A: s = 1 .. na (row k+bw is phase B's, except at k = 0 where it is already resident)
+    const int na = (k == 0 || nb < bw) ? nb : bw - 1;
     const double zk = z[k];
-    // trailing update of rows k+1 .. k+nb (upper triangle s <= t of the nb x nb block) and of z
-    for (int idx = c.tid(); idx < nb * nb; idx += NT) {
-      const int s0 = idx / nb, t0 = idx - s0 * nb;
-      if (t0 < s0) continue;
-      const int s = s0 + 1, t = t0 + 1;
-      double* row = win + ((k + s) % ld) * ld;
-      row[t - s] -= wk[s] * inv * wk[t];
+    if (na > 0) {
+      // upper triangle s <= t of the na x nb block, flat index walked without per-element division
+      const int qn = NT / nb, rn = NT - qn * nb;
+      int s0 = c.tid() / nb, t0 = c.tid() - s0 * nb;
+      while (s0 < na) {
+        if (t0 >= s0) {
+          const int sft = s0 + 1, tt = t0 + 1;
+          double* row = win + ((k + sft) % ld) * ld;
+          row[tt - sft] -= wk[sft] * inv * wk[tt];
+        }
+        s0 += qn;
+        t0 += rn;
+        if (t0 >= nb) { t0 -= nb; ++s0; }
+      }
     }
     for (int s = 1 + c.tid(); s <= nb; s += NT) z[k + s] -= wk[s] * inv * zk;
-    c.sync();
-    // retire row k to the factor, bring row k + ld into its slot
-    for (int t = c.tid(); t <= bw; t += NT) {
-      fac[k * ld + t] = (t == 0) ? inv : wk[t];
-      wk[t] = band_row_entry(Hb, ld, act, p, reg, k + ld, t);
+    if (k > 0) {
+      double* wp = win + ((k - 1) % ld) * ld;
+      for (int t = c.tid(); t <= bw; t += NT) {
+        fac[(k - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
+        double nv = (t == c.tid()) ? pre : band_row_entry(Hb, ld, act, p, reg, k - 1 + ld, t);
+        if (t == 0 && k + bw < p) nv -= wk[bw] * inv * wk[bw];
+        wp[t] = nv;
+      }
     }
+    inv_prev = inv;
+    if (c.tid() <= bw) pre = band_row_entry(Hb, ld, act, p, reg, k + ld, c.tid());  // for step k + 1
     c.sync();
   }
-  // back substitution  x_k = inv_k * (z_k - sum_s fac[k][s] * x_{k+s})
-  for (int k = p - 1; k >= 0; --k) {
-    const int nb = bw < p - 1 - k ? bw : p - 1 - k;
-    double part = 0.0;
-    for (int s = 1 + c.tid(); s <= nb; s += NT) part += fac[k * ld + s] * x[k + s];
-    part = c.reduce_sum(part);
-    if (c.tid() == 0) x[k] = fac[k * ld] * (z[k] - part);
-    c.sync();
+  {
+    const double* wp = win + ((p - 1) % ld) * ld;
+    for (int t = c.tid(); t <= bw; t += NT) fac[(p - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
   }
+  c.sync();
+  // back substitution  x_k = inv_k * (z_k - sum_s fac[k][s] * x_{k+s}), by the first wave alone:
+  // no barriers, the next factor row is loaded while the current one is reduced
+  if (c.wave_id() == 0) {
+    constexpr int WL = C::WL;
+    const int lane = c.lane_id();
+    const int nchunk = (bw + WL - 1) / WL;  // lanes cover s = 1 + lane + j*WL
+    if (nchunk <= 1) {
+      double fnext = (1 + lane <= bw && p - 1 >= 0) ? fac[(p - 1) * ld + 1 + lane] : 0.0;
+      for (int k = p - 1; k >= 0; --k) {
+        const int nb = bw < p - 1 - k ? bw : p - 1 - k;
+        const double fk = fnext;
+        if (k > 0) fnext = (1 + lane <= bw) ? fac[(k - 1) * ld + 1 + lane] : 0.0;
+        double part = (1 + lane <= nb) ? fk * x[k + 1 + lane] : 0.0;
+        part = c.wave_sum(part);
+        if (lane == 0) x[k] = fac[k * ld] * (z[k] - part);
+        c.wave_fence();
+      }
+    } else {
+      for (int k = p - 1; k >= 0; --k) {
+        const int nb = bw < p - 1 - k ? bw : p - 1 - k;
+        double part = 0.0;
+        for (int s = 1 + lane; s <= nb; s += WL) part += fac[k * ld + s] * x[k + s];
+        part = c.wave_sum(part);
+        if (lane == 0) x[k] = fac[k * ld] * (z[k] - part);
+        c.wave_fence();
+      }
+    }
+  }
+  c.sync();
 }
 
 }  // namespace cave

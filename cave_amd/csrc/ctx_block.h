@@ -48,6 +48,12 @@ struct BlockCtx {
   // sum / max over the lanes of the calling wave only (no barrier; every lane gets the result)
   __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
   __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
+  // make this wave's earlier stores visible to its own later loads issued by other lanes
+  __device__ __forceinline__ void wave_fence() const {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
 
   __device__ __forceinline__ double reduce_sum(double v) {

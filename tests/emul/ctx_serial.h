@@ -24,6 +24,7 @@ struct SerialCtx {
   int lane_id() const { return 0; }
   double wave_sum(double v) const { return v; }
   double wave_max(double v) const { return v; }
+  void wave_fence() const {}
   void sync() const {}
   double reduce_sum(double v) const { return v; }
   double reduce_max(double v) const { return v; }

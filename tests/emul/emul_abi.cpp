@@ -85,6 +85,16 @@ int32_t cave_emul_cone_packed(const cave_cone_store* store, const int64_t* ids, 
   return CAVE_OK;
 }
 
+// band LDL^T solver alone (cone_band.h): Hb [p*(bw+1)] band form, x out
+int32_t cave_emul_band_solve(const double* Hb, int32_t bw, const double* rhs, const uint8_t* act, int32_t p,
+                             double reg_rel, double* x) {
+  const size_t ld = (size_t)bw + 1;
+  std::vector<double> win(ld * ld), fac((size_t)(p > 0 ? p : 1) * ld), z((size_t)(p > 0 ? p : 1));
+  SerialCtx c;
+  solve_spd_band(c, Hb, bw, rhs, act, p, reg_rel, win.data(), fac.data(), z.data(), x);
+  return CAVE_OK;
+}
+
 // ---- large-cone path: one serial "workgroup", arena = heap slice, hot arena = lds_bytes of heap
 
 int64_t cave_emul_large_slice_bytes(int64_t m_max, int64_t d, int64_t nnz_cap, int64_t band_entries) {

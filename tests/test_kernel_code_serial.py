@@ -125,7 +125,81 @@ def test_asan_ubsan_clean():
         "r = np.random.default_rng(0); A = r.standard_normal((3,9,5)).astype(np.float32)\n"
         "E.cone_dense(A, r.standard_normal((3,5)).astype(np.float32), 2)\n"
         "E.cone_dense(A, r.standard_normal((3,5)).astype(np.float32), 0, nnz_cap=8)\n"  # overflow path
+        "for mode in range(5): E.cone_dense_large(c, y, mode)\n"  # large-cone path: exact-size workspace slice
+        "E.cone_dense_large(A, r.standard_normal((3,5)).astype(np.float32), 2, lds_bytes=1024)\n"
+        "E.cone_dense_large(c, y, 0, slice_bytes=20000)\n"  # workspace too small -> TOO_LARGE, no overrun
+        "c2,y2,_ = synth.sp_batch(9, 9, 2, 1)\n"
+        "st,arrs,mr,mz = E.pack_large(c2); E.cone_packed_large(st,arrs,mr,np.arange(2),y2,2)\n"
         "print('asan-ok')\n" % (ROOT, os.path.join(ROOT, "tests"), so))
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "asan-ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_band_solver_matches_dense_solve(emul):
+    """cone_band.h: LDL^T band elimination == dense solve of the masked system (identity rows for
+    fixed unknowns, H + reg*I on the free block), over random bandwidths, masks and sizes."""
+    import ctypes as C
+    E = emul
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        p = int(rng.integers(1, 70))
+        bw = int(rng.integers(0, p)) if trial % 3 else p - 1
+        ld = bw + 1
+        G = rng.standard_normal((p, p + 3))
+        H = G @ G.T
+        for i in range(p):
+            for j in range(p):
+                if abs(i - j) > bw:
+                    H[i, j] = 0.0
+        H += np.eye(p) * (np.abs(H).sum(1).max() if bw < p - 1 else 0.0)  # keep the truncated band SPD
+        act = (rng.random(p) < 0.25).astype(np.uint8)
+        rhs = rng.standard_normal(p)
+        Hb = np.zeros((p, ld))
+        for j in range(p):
+            for t in range(ld):
+                if j + t < p:
+                    Hb[j, t] = H[j + t, j]
+        x = np.zeros(p)
+        reg_rel = 1e-10
+        rc = E.lib.cave_emul_band_solve(Hb.ctypes.data_as(C.c_void_p), C.c_int32(bw), rhs.ctypes.data_as(C.c_void_p),
+                                        act.ctypes.data_as(C.c_void_p), C.c_int32(p), C.c_double(reg_rel),
+                                        x.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        free = act == 0
+        Md = np.eye(p)
+        reg = reg_rel * (H.diagonal()[free].max() if free.any() else 0.0)
+        Md[free] = H[free]
+        Md[free, free] += reg
+        # fixed unknowns: x = rhs; free rows: H_FF x_F + H_FA x_A = rhs_F
+        want = np.linalg.solve(Md, rhs)
+        assert np.allclose(x, want, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(want).max())), (trial, p, bw)
+
+
+def large_impl(E):
+    def f(ctrs, costs, mode, sign, inner_ratio):
+        return E.cone_dense_large(ctrs, costs, mode, sign=sign, inner_ratio=inner_ratio)
+    return f
+
+
+@pytest.mark.parametrize("file,tag", CASES)
+def test_large_path_code_matches_reference_outputs(emul, golden, file, tag):
+    """The large-cone path (global-workspace arena, band Newton systems, smoothed Hessian) must give the
+    reference's outputs on the same fixtures as the fast path."""
+    check_case(large_impl(emul), golden, file, tag)
+
+
+def test_large_path_packed_equals_dense(emul):
+    from cave_amd import synth
+    ctrs, costs, _ = synth.sp_batch(9, 9, 6, seed=4)   # 81 reduced rows: beyond the register solver
+    dense = emul.cone_dense_large(ctrs, costs, MODE_INNER, sign=-1.0)
+    st, arrs, mr, mz = emul.pack_large(ctrs)
+    assert mr == 81
+    packed = emul.cone_packed_large(st, arrs, mr, np.arange(6)[::-1].copy(), costs[::-1].copy(), MODE_INNER, sign=-1.0)
+    assert (dense["status"] == 0).all() and (packed["status"] == 0).all()
+    for k in ("loss", "grad", "target"):
+        assert np.allclose(dense[k][::-1], packed[k], rtol=0, atol=2e-6), k
+    po, ro = O.batch_project(-costs, ctrs)
+    pr = emul.cone_dense_large(ctrs, costs, MODE_PROJECT, sign=-1.0)
+    assert np.abs(pr["proj"] - po).max() < 2e-6 and np.abs(pr["rnorm"] - ro).max() < 2e-6
+    assert int(pr["iters"].max()) <= 15
