@@ -111,7 +111,16 @@ __global__ __launch_bounds__(CtxL::NT, 2) void cone_packed_large_kernel(PackedPa
   c.init(smem);
   unsigned char* ws = W.base + (uint64_t)blockIdx.x * W.slice;
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
+#ifdef CAVE_STAMPS
+    for (int i = 0; i < 16; ++i) c.st[i] = 0;
+    unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     run_packed_large_instance<CtxL>(c, smem, P, b, ws, (uint32_t)W.slice);
+#ifdef CAVE_STAMPS
+    c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
+    c.st[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
+    if (c.tid() == 0 && b < 8192) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
+#endif
     __syncthreads();
   }
 }

@@ -5,8 +5,8 @@
 // order) have half bandwidth = grid width, TSP degree rows give a dense matrix (bw = p - 1, p ~ n).
 // The solver is an LDL^T elimination of the band without pivoting, written against the Ctx interface:
 // a ring window of bw+1 band rows (LDS when it fits) is updated by the whole workgroup, one barrier
-// per phase; eliminated rows stream out to `bfac`; the right-hand side is eliminated alongside; the
-// back substitution runs over `bfac`.
+// per pivot; eliminated rows stream out to `bfac`; the right-hand side is eliminated alongside; the
+// back substitution streams `bfac` back in.
 //
 // Semantics are those of gj_solve (wave_prims.h): rows flagged `act` are identity rows (x = rhs),
 // free rows are rows of H + reg_rel*max diag*I; a non-positive pivot drops its row/column (x_k = 0).
@@ -21,7 +21,8 @@ CAVE_HD double band_at(const double* Hb, int ld, int i, int j) {
 }
 
 // masked + shifted entry t of band row r as the elimination sees it
-CAVE_HD double band_row_entry(const double* Hb, int ld, const uint8_t* act, int p, double reg, int r, int t) {
+template <class PH, class PA>
+CAVE_HD double band_row_entry(PH Hb, int ld, PA act, int p, double reg, int r, int t) {
   const int i = r + t;
   if (r >= p || i >= p) return 0.0;
   const bool fixed = act[r] || act[i];
@@ -29,12 +30,37 @@ CAVE_HD double band_row_entry(const double* Hb, int ld, const uint8_t* act, int 
   return fixed ? 0.0 : Hb[r * ld + t];
 }
 
+// rows staged per chunk (see solve_spd_band): bounded by the per-thread prefetch registers
 template <class C>
-CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, const uint8_t* act, int p,
-                            double reg_rel, double* win, double* fac, double* z, double* x) {
-  const int NT = C::NT;
+CAVE_HD int band_chunk_rows(int ld) {
+  constexpr int RMAX = (C::NT >= 64) ? 16 : 4096;
+  const int byregs = (RMAX * C::NT) / ld;
+  return byregs < 32 ? byregs : 32;
+}
+
+// HOT: win, z, x, stg and act are in LDS (typed ds_* accesses, barriers that wait for LDS only), Hb and
+// fac in the global workspace.  Nothing inside the two sequential loops waits for global memory: rows
+// of H (then of the factor) are fetched a chunk of CH rows ahead into registers and parked in the LDS
+// staging buffers `stg` [2][CH*ld] one chunk before they are needed; factor rows are stored and forgotten.
+// (A real call, not inlined: inside the fully inlined Newton iteration its loops inherit a register file
+// already spilling; as a function they get their own allocation.)
+template <class C, bool HOT>
+CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double* rhs, const uint8_t* act_, int p,
+                            double reg_rel, double* win_, double* fac_, double* z_, double* x_, double* stg_, int CH) {
+  constexpr int NT = C::NT;
+  constexpr int RMAX = (NT >= 64) ? 16 : 4096;
+  constexpr int HS = HOT ? 3 : 0;   // space of the hot arrays
+  constexpr int GS = HOT ? 1 : 0;   // HOT is only used on the GPU path, where Hb / fac are workspace (global) memory
   const int ld = bw + 1;
   if (p <= 0) return;
+  CAVE_T0();
+  auto Hb = space_cast<GS>(Hb_);
+  auto fac = space_cast<GS>(fac_);
+  auto act = space_cast<HS>(act_);
+  auto win = space_cast<HS>(win_);
+  auto z = space_cast<HS>(z_);
+  auto x = space_cast<HS>(x_);
+  auto stg = space_cast<HS>(stg_);
   double md = 0.0;
   uint32_t nfix = 0;
   for (int i = c.tid(); i < p; i += NT) {
@@ -50,7 +76,7 @@ CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, c
     if (nfix != 0u && !act[i]) {
       const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
       for (int j = j0; j <= j1; ++j)
-        if (act[j]) zi -= band_at(Hb, ld, i, j) * rhs[j];
+        if (act[j]) zi -= ((i >= j) ? Hb[j * ld + (i - j)] : Hb[i * ld + (j - i)]) * rhs[j];
     }
     z[i] = zi;
   }
@@ -62,20 +88,46 @@ CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, c
     c.sync();
     return;
   }
-  // ring window: band row r lives in slot r % ld
+  const int csz = CH * ld;  // entries per staged chunk
+  double regs[RMAX];
+  // entries [e0, e0 + csz) of a global array (clipped at eend) -> registers / registers -> staging buffer b
+  auto fetch = [&](decltype(Hb) src, int e0, int eend) {
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      const int idx = c.tid() + j * NT;
+      if (idx < csz) regs[j] = (e0 + idx < eend) ? src[e0 + idx] : 0.0;
+    }
+  };
+  auto fetch_h = [&](int r0) { fetch(Hb, r0 * ld, p * ld); };  // raw rows r0 .. r0+CH-1 of H (masked on insertion)
+  auto park = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      const int idx = c.tid() + j * NT;
+      if (idx < csz) stg[b * csz + idx] = regs[j];
+    }
+  };
+  // ring window: band row r lives in slot r % ld; rows ld .. p-1 arrive through the staging buffers
   for (int idx = c.tid(); idx < ld * ld; idx += NT) {
     const int r = idx / ld, t = idx - r * ld;
     win[idx] = band_row_entry(Hb, ld, act, p, reg, r, t);
   }
+  const bool streaming = p > ld;
+  if (streaming) {
+    fetch_h(ld);
+    park(0);
+    fetch_h(ld + CH);  // chunk 1 stays in registers until chunk 0 starts being consumed
+  }
   // One barrier per pivot.  Step k: (A) pivot k updates rows k+1 .. k+bw-1 of the window and z;
   // (B) row k-1, final since the previous barrier, is retired to the factor and its slot takes row
   // k+bw of H -- the one row pivot k reaches only in its diagonal entry, which the inserting thread
-  // adjusts itself.  A and B touch disjoint slots.  The H row for step k+1 is loaded one step ahead.
-  double pre = (c.tid() <= bw) ? band_row_entry(Hb, ld, act, p, reg, ld, c.tid()) : 0.0;  // row 0 + ld, for step 1
+  // adjusts itself.  A and B touch disjoint slots.
   double inv_prev = 0.0;
   c.sync();
+  CAVE_ACC(10);
+  int slot_k = 0;          // k % ld, kept incrementally
+  int cpos = 0, cidx = 0;  // position of the row inserted at this step inside its chunk, chunk index
   for (int k = 0; k < p; ++k) {
-    double* wk = win + (k % ld) * ld;
+    auto wk = win + slot_k * ld;
     const double dk = wk[0];
     const bool ok = dk > 1e-300;
     const double inv = ok ? 1.0 / dk : 0.0;
@@ -90,7 +142,9 @@ CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, c
       while (s0 < na) {
         if (t0 >= s0) {
           const int sft = s0 + 1, tt = t0 + 1;
-          double* row = win + ((k + sft) % ld) * ld;
+          int slot = slot_k + sft;
+          if (slot >= ld) slot -= ld;
+          auto row = win + slot * ld;
           row[tt - sft] -= wk[sft] * inv * wk[tt];
         }
         s0 += qn;
@@ -100,52 +154,70 @@ CAVE_HD void solve_spd_band(C& c, const double* Hb, int bw, const double* rhs, c
     }
     for (int s = 1 + c.tid(); s <= nb; s += NT) z[k + s] -= wk[s] * inv * zk;
     if (k > 0) {
-      double* wp = win + ((k - 1) % ld) * ld;
+      auto wp = win + (slot_k == 0 ? bw : slot_k - 1) * ld;
+      const bool ins = streaming && (k - 1 + ld < p);
+      if (ins && cpos == 0) {
+        // first row of chunk cidx: chunk cidx+1 (in registers) takes the buffer chunk cidx-1 has just left
+        park((cidx + 1) & 1);
+        fetch_h(ld + (cidx + 2) * CH);
+      }
+      auto src = stg + (cidx & 1) * csz + cpos * ld;
       for (int t = c.tid(); t <= bw; t += NT) {
         fac[(k - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
-        double nv = (t == c.tid()) ? pre : band_row_entry(Hb, ld, act, p, reg, k - 1 + ld, t);
+        double nv = 0.0;
+        if (ins) {  // row rI = k + bw of H as the elimination sees it (band_row_entry on the staged raw row)
+          const int rI = k + bw, i = rI + t;
+          const double raw = src[t];
+          if (i < p) nv = (t == 0) ? (act[rI] ? 1.0 : raw + reg) : ((act[rI] || act[i]) ? 0.0 : raw);
+        }
         if (t == 0 && k + bw < p) nv -= wk[bw] * inv * wk[bw];
         wp[t] = nv;
       }
+      if (ins && ++cpos == CH) { cpos = 0; ++cidx; }
     }
     inv_prev = inv;
-    if (c.tid() <= bw) pre = band_row_entry(Hb, ld, act, p, reg, k + ld, c.tid());  // for step k + 1
-    c.sync();
+    if (++slot_k == ld) slot_k = 0;
+    if constexpr (HOT) c.sync_lds();
+    else c.sync();
   }
   {
-    const double* wp = win + ((p - 1) % ld) * ld;
+    auto wp = win + ((p - 1) % ld) * ld;
     for (int t = c.tid(); t <= bw; t += NT) fac[(p - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
   }
-  c.sync();
-  // back substitution  x_k = inv_k * (z_k - sum_s fac[k][s] * x_{k+s}), by the first wave alone:
-  // no barriers, the next factor row is loaded while the current one is reduced
-  if (c.wave_id() == 0) {
-    constexpr int WL = C::WL;
-    const int lane = c.lane_id();
-    const int nchunk = (bw + WL - 1) / WL;  // lanes cover s = 1 + lane + j*WL
-    if (nchunk <= 1) {
-      double fnext = (1 + lane <= bw && p - 1 >= 0) ? fac[(p - 1) * ld + 1 + lane] : 0.0;
-      for (int k = p - 1; k >= 0; --k) {
-        const int nb = bw < p - 1 - k ? bw : p - 1 - k;
-        const double fk = fnext;
-        if (k > 0) fnext = (1 + lane <= bw) ? fac[(k - 1) * ld + 1 + lane] : 0.0;
-        double part = (1 + lane <= nb) ? fk * x[k + 1 + lane] : 0.0;
-        part = c.wave_sum(part);
-        if (lane == 0) x[k] = fac[k * ld] * (z[k] - part);
-        c.wave_fence();
-      }
-    } else {
-      for (int k = p - 1; k >= 0; --k) {
+  c.sync();  // full barrier: the factor rows are in (workgroup-visible) global memory now
+  CAVE_ACC(11);
+  // back substitution  x_k = inv_k * (z_k - sum_s fac[k][s] * x_{k+s}): factor rows come back through the
+  // staging buffers, CH rows per barrier, and the first wave does the sequential part without barriers
+  // chunk j holds rows klo .. khi (ascending), khi = p-1 - j*CH
+  auto fetch_f = [&](int khi) {
+    const int klo = khi - CH + 1 > 0 ? khi - CH + 1 : 0;
+    fetch(fac, klo * ld, (khi + 1) * ld);
+  };
+  fetch_f(p - 1);
+  int b = 0;
+  for (int khi = p - 1; khi >= 0; khi -= CH, b ^= 1) {
+    park(b);
+    if (khi - CH >= 0) fetch_f(khi - CH);
+    if constexpr (HOT) c.sync_lds();
+    else c.sync();
+    if (c.wave_id() == 0) {
+      constexpr int WL = C::WL;
+      const int lane = c.lane_id();
+      const int klo = khi - CH + 1 > 0 ? khi - CH + 1 : 0;
+      for (int k = khi; k >= klo; --k) {
+        auto fk = stg + b * csz + (k - klo) * ld;
         const int nb = bw < p - 1 - k ? bw : p - 1 - k;
         double part = 0.0;
-        for (int s = 1 + lane; s <= nb; s += WL) part += fac[k * ld + s] * x[k + s];
+        for (int s = 1 + lane; s <= nb; s += WL) part += fk[s] * x[k + s];
         part = c.wave_sum(part);
-        if (lane == 0) x[k] = fac[k * ld] * (z[k] - part);
-        c.wave_fence();
+        if (lane == 0) x[k] = fk[0] * (z[k] - part);
+        if constexpr (HOT) c.wave_fence_lds();
+        else c.wave_fence();
       }
     }
   }
   c.sync();
+  CAVE_ACC(12);
 }
 
 }  // namespace cave

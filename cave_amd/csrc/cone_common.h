@@ -13,8 +13,10 @@
 
 #if defined(__HIPCC__)
 #define CAVE_HD __device__ __forceinline__
+#define CAVE_NOINLINE __device__ __noinline__  // own register allocation (cone_band.h)
 #else
 #define CAVE_HD inline
+#define CAVE_NOINLINE inline
 #endif
 
 // ---- optional phase timing (diagnostic builds only: -DCAVE_STAMPS; never in the shipped library).
@@ -29,6 +31,19 @@
 #endif
 
 namespace cave {
+
+// Address-space-typed pointers for the large-cone path.  Its arenas hand out generic pointers (an
+// array may sit in LDS or in the global workspace), which compile to FLAT memory operations: those
+// count on both wait counters, so every LDS access would also wait for outstanding HBM traffic.
+// Code that knows where an array lives casts once and gets ds_* / global_* instructions.
+template <class T, int SPACE>  // SPACE: 0 generic, 1 global, 3 LDS
+struct SpacePtr { using type = T*; };
+#if defined(__HIPCC__)
+template <class T> struct SpacePtr<T, 1> { using type = __attribute__((address_space(1))) T*; };
+template <class T> struct SpacePtr<T, 3> { using type = __attribute__((address_space(3))) T*; };
+#endif
+template <int SPACE, class T>
+CAVE_HD typename SpacePtr<T, SPACE>::type space_cast(T* q) { return (typename SpacePtr<T, SPACE>::type)q; }
 
 // per-instance status codes (also in include/cave_hip.h)
 enum : int32_t {
@@ -82,6 +97,10 @@ struct Arena {
     return reinterpret_cast<T*>(base + top);
   }
   CAVE_HD void release_top() { top = cap; }
+  CAVE_HD bool owns(const void* q) const {
+    const unsigned char* u = (const unsigned char*)q;
+    return u >= base && u < base + cap;
+  }
   // like get(), but a request that does not fit returns null and leaves the arena untouched
   template <class T>
   CAVE_HD T* try_get(uint32_t n) {
@@ -128,10 +147,13 @@ struct SolveWork {
   uint8_t* dflag;  // [d]  coordinates currently counted in H
   int ldh;
   // band form only (large-cone path, cone_band.h)
+  bool band_hot;   // bwin, bz, step and act all live in LDS (typed fast variant of the band solver)
   int bw;          // half bandwidth of M M^T in the reduced-row order
   double* bwin;    // [(bw+1)*(bw+1)] ring window of the rows being eliminated
   double* bfac;    // [p*(bw+1)] factor: bfac[k*ldh] = 1/d_k, bfac[k*ldh + t] = row k of the updated band
   double* bz;      // [p] right-hand side being eliminated
+  double* bstg;    // [2*bch*(bw+1)] staging buffers for rows streamed from / to the workspace
+  int bch;         // rows per staged chunk
 };
 
 struct SolveResult {

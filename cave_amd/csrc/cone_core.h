@@ -633,7 +633,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         for (int i = c.tid(); i < p; i += NT) rhs[i] = w.act[i] ? -tc[i] : -w.dv[i];
         c.sync();
         CAVE_ACC(4);
-        if constexpr (BAND) solve_spd_band(c, w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step);
+        if constexpr (BAND) {
+          if (w.band_hot)
+            solve_spd_band<C, true>(c, w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);
+          else
+            solve_spd_band<C, false>(c, w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);
+        }
         else c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
         c.sync();
         CAVE_ACC(5);

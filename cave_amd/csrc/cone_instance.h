@@ -155,19 +155,26 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     const uint32_t pp = (uint32_t)(p > 0 ? p : 1);
     SolveWork w;
     w.y = y;
-    w.bw = 0; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr;
+    w.bw = 0; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
     if constexpr (LARGE) {
       const int bw = band_halfwidth(c, v);
       const uint32_t ld = (uint32_t)bw + 1u;
-      if ((uint64_t)pp * ld > (1ull << 27)) return ST_TOO_LARGE;  // 1 GiB of band per instance
+      if ((uint64_t)pp * ld > (1ull << 27) || ld > 4096u) return ST_TOO_LARGE;  // 1 GiB of band per instance
       w.bw = bw;
       w.ldh = (int)ld;
       // small, touched every elimination step / every inner round: LDS first
       w.bwin = hot_get<double>(hot, ar, ld * ld);
       w.bz = hot_get<double>(hot, ar, pp);
       w.step = hot_get<double>(hot, ar, pp);
-      w.g2 = hot_get<double>(hot, ar, pp);
       w.act = hot_get<uint8_t>(hot, ar, pp);
+      // staging chunks: as many rows as the prefetch registers hold, fewer if that keeps them in LDS
+      w.bch = band_chunk_rows<C>((int)ld);
+      if (hot) {
+        const uint32_t room = (hot->top - hot->off) / (2u * 8u * ld);
+        if (room >= 4u && room < (uint32_t)w.bch) w.bch = (int)room;
+      }
+      w.bstg = hot_get<double>(hot, ar, 2u * (uint32_t)w.bch * ld);
+      w.g2 = hot_get<double>(hot, ar, pp);
       w.ttry = hot_get<double>(hot, ar, pp);
       w.dv = hot_get<double>(hot, ar, pp);
       w.theta = hot_get<double>(hot, ar, pp);
@@ -178,6 +185,10 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.dflag = hot_get<uint8_t>(hot, ar, d);
       w.H = ar.get<double>(pp * ld);
       w.bfac = ar.get<double>(pp * ld);
+#if defined(__HIPCC__)
+      w.band_hot = hot && hot->owns(w.bwin) && hot->owns(w.bz) && hot->owns(w.step) && hot->owns(w.act) &&
+                   hot->owns(w.bstg);
+#endif
     } else {
       if (p > C::PMAX) return ST_TOO_LARGE;
       w.rc = ar.get<double>(d);
@@ -500,7 +511,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
                    (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d)) + align8u(4 * p);
   uint64_t vecs = 2 * align8u(4 * d);
   uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) + align8u(4 * p) +
-                   3 * (uint64_t)8 * (uint64_t)(band + 1);  // H, factor, ring window ((bw+1)^2 <= p*(bw+1))
+                   3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 32 * 8 * (uint64_t)(band / (p > 0 ? p : 1) + 2) + 8 * 2 * 32 * 4096;  // H, factor, ring window ((bw+1)^2 <= p*(bw+1)), staging
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 256;
@@ -508,7 +519,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
 static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band) {
   const int64_t p = max_rows > 0 ? max_rows : 1;
   return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) +
-         align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 256;
+         align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 8 * 2 * 32 * 4096 + 256;
 }
 
 static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false) {

@@ -48,6 +48,12 @@ struct BlockCtx {
   // sum / max over the lanes of the calling wave only (no barrier; every lane gets the result)
   __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
   __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
+  // barrier that orders LDS traffic only (typed ds_* accesses): does not wait for global loads / stores in flight
+  __device__ __forceinline__ void sync_lds() const {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  // LDS-only form of wave_fence (ds operations of one wave execute in order)
+  __device__ __forceinline__ void wave_fence_lds() const { asm volatile("" ::: "memory"); }
   // make this wave's earlier stores visible to its own later loads issued by other lanes
   __device__ __forceinline__ void wave_fence() const {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

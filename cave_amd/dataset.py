@@ -146,7 +146,11 @@ class ConeStore:
         # cones beyond the LDS-resident solver (more than 64 reduced rows or too many non-zeros) run on the
         # large-cone path, which reads the store in place and keeps the Newton systems as bands
         self.large = self.lds_bytes <= 0 or self.max_rows > 64
-        self.band_entries = self._max_band_entries() if self.large else 0
+        self.band_entries, self.max_bw = self._max_band_entries() if self.large else (0, 0)
+        # LDS for the large path's hot arrays: ring window + staging buffers + three row vectors
+        ld = self.max_bw + 1
+        want = 8 * (ld * ld + 2 * 32 * ld + 3 * self.max_rows) + self.max_rows + 4096
+        self.large_lds = int(min(_lib.MAX_LDS, max(32 * 1024, (want + 4095) // 4096 * 4096)))
         return self
 
     def _max_band_entries(self) -> int:
@@ -154,7 +158,7 @@ class ConeStore:
         (half bandwidth = widest span of reduced-row indices meeting in one column of the CSC)."""
         t, d, N = self.t, self.d, self.n
         if N == 0 or self.max_nnz == 0:
-            return 1
+            return 1, 0
         cptr = t["cptr"].view(N, d + 1).to(torch.int64)
         base = t["nnz_off"][:-1, None]
         lo, hi = cptr[:, :-1] + base, cptr[:, 1:] + base
@@ -164,7 +168,7 @@ class ConeStore:
         span = torch.where(hi > lo, last - first, torch.zeros_like(lo))
         bw = span.max(dim=1).values
         rows = t["row_off"][1:] - t["row_off"][:-1]
-        return int((rows * (bw + 1)).max().item())
+        return int((rows * (bw + 1)).max().item()), int(bw.max().item())
 
     # -------------------------------------------------------------------- use
     def _waves_for(self, B: int) -> int:
@@ -210,7 +214,7 @@ class ConeStore:
                 ws = _lib.workspace(dev, slots * slice_bytes)
                 rc = lib.cave_hip_cone_packed_large(
                     C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                    int(max_iter), 0, _lib.ptr(ws), slice_bytes, slots,
+                    int(max_iter), self.large_lds, _lib.ptr(ws), slice_bytes, slots,
                     _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())

@@ -126,6 +126,10 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
                 _lib.current_stream())
             _lib.check(rc, "cave_hip_cone_dense")
 
+        # LDS of the large path's hot arrays (band window + staging).  The band is only known inside the
+        # kernel: wide cost vectors go with dense reduced systems (TSP: ~sqrt(2d) rows, window ~16 d bytes)
+        large_lds = _lib.MAX_LDS if d >= 4096 else 64 * 1024
+
         def launch_large(cap: int, band: int) -> None:
             slice_bytes = int(lib.cave_hip_large_slice_bytes(m, d, cap, band))
             if slice_bytes <= 0 or slice_bytes >= 1 << 32:
@@ -135,7 +139,7 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             ws = _lib.workspace(dev, slots * slice_bytes)
             rc = lib.cave_hip_cone_dense_large(
                 _lib.ptr(ctrs), _lib.ptr(pred), B, m, d, int(mode), float(sign), float(inner_ratio),
-                int(max_iter), int(cap), 0, _lib.ptr(ws), slice_bytes, slots,
+                int(max_iter), int(cap), large_lds, _lib.ptr(ws), slice_bytes, slots,
                 _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                 _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                 _lib.current_stream())

@@ -23,4 +23,5 @@ def golden():
         "structured": np.load(os.path.join(d, "structured.npz")),
         "tsp50": np.load(os.path.join(d, "tsp50.npz")),
         "scipy_defect": np.load(os.path.join(d, "scipy_defect.npz")),
+        "large": np.load(os.path.join(d, "large.npz")),
     }

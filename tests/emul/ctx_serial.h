@@ -18,13 +18,15 @@ struct SerialCtx {
   double team_reduce_sum(double v) const { return v; }
   static constexpr int PMAX = 64;
   static constexpr int NWAVES = 1;
-  static constexpr int WL = 1;
+  static constexpr int WL = 1;  // single lane: the back substitution takes its strided form
   int tid() const { return 0; }
   int wave_id() const { return 0; }
   int lane_id() const { return 0; }
   double wave_sum(double v) const { return v; }
   double wave_max(double v) const { return v; }
   void wave_fence() const {}
+  void wave_fence_lds() const {}
+  void sync_lds() const {}
   void sync() const {}
   double reduce_sum(double v) const { return v; }
   double reduce_max(double v) const { return v; }

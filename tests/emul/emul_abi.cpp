@@ -91,7 +91,10 @@ int32_t cave_emul_band_solve(const double* Hb, int32_t bw, const double* rhs, co
   const size_t ld = (size_t)bw + 1;
   std::vector<double> win(ld * ld), fac((size_t)(p > 0 ? p : 1) * ld), z((size_t)(p > 0 ? p : 1));
   SerialCtx c;
-  solve_spd_band(c, Hb, bw, rhs, act, p, reg_rel, win.data(), fac.data(), z.data(), x);
+  int ch = band_chunk_rows<SerialCtx>((int)ld);
+  if (ch > 3) ch = 3;  // small chunks: exercise the chunk hand-over often
+  std::vector<double> stg(2 * (size_t)ch * ld);
+  solve_spd_band<SerialCtx, false>(c, Hb, bw, rhs, act, p, reg_rel, win.data(), fac.data(), z.data(), x, stg.data(), ch);
   return CAVE_OK;
 }
 

@@ -1,0 +1,26 @@
+"""Diagnostic: per-phase cycle shares of cone_packed_large_kernel (stamps build; never quote its run time)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from cave_amd import _lib, synth
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcave_hip_stamps.so")
+from cave_amd.dataset import ConeStore
+lib = _lib.load()
+names = ["scan+build", "load y/avg", "grad+pgn", "hessian", "inner misc", "solve_spd total", "ls setup + gather q",
+         "ls dphi loop + theta update", "gather r + f", "epilogue(+solve total tail)", "  band prep (z, window)", "  band factor loop",
+         "  band back-subst", "-"]
+which = sys.argv[1] if len(sys.argv) > 1 else "sp30"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+if which == "sp30": ctrs, costs, _ = synth.sp_batch(30, 30, B, seed=0)
+else: ctrs, costs, _ = synth.tsp_batch(100, B, seed=0)
+c = torch.tensor(ctrs, device="cuda"); p = torch.tensor(costs, device="cuda")
+st = ConeStore.from_dense(c, chunk=8)
+ids = torch.arange(B, device="cuda")
+for _ in range(2): o = st.cone_op(ids, p, 0, -1.0)
+buf = (C.c_ulonglong * (16 * B))()
+lib.cave_hip_debug_stamps(buf, B)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(B, 16).astype(np.float64)
+mean = a.mean(0); tot = mean[14]
+print(f"{which} B={B}: iters mean {o['iters'].float().mean():.2f}; cycles/instance {tot:.0f} = {mean[15]/100:.1f} us")
+for i, n in enumerate(names):
+    print(f"  {n:45s} {mean[i]:12.0f}  {100*mean[i]/tot:5.1f}%")
