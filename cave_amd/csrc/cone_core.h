@@ -54,6 +54,15 @@ struct ConeBuild {
   int n_valid_avg;
 };
 
+// Smoothed generalised Hessian (see solve_cone_impl) on the LDS-resident fast path too?  Measured on
+// TSP-20: the iteration count tightens (max 10 -> 8 over 512 instances, mean unchanged) but rebuilding H
+// every iteration costs more than the incremental +-1 updates save: 238 -> 248 us at B = 1024 and
+// 333 -> 584 us at B = 4096 (packed).  Off; the large-cone path, where it is 10x fewer iterations, has it.
+#ifndef CAVE_SMOOTH_FAST
+#define CAVE_SMOOTH_FAST 0
+#endif
+static constexpr bool kSmoothFast = CAVE_SMOOTH_FAST != 0;
+
 static constexpr uint32_t kHashPrefix = 12;
 static constexpr uint32_t kLongRow = 64;   // rows longer than this are handled by the whole team, one at a time
 static constexpr uint8_t ROW_PM1 = 0x20;   // every entry of the row is +-1
@@ -506,10 +515,10 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   for (int k = c.tid(); k < d; k += NT) {
     yy += (double)w.y[k] * (double)w.y[k];
     r[k] = (double)w.y[k];
-    if constexpr (BAND) ymax = fmax(ymax, fabs((double)w.y[k]));
+    if constexpr (BAND || kSmoothFast) ymax = fmax(ymax, fabs((double)w.y[k]));
   }
   yy = c.reduce_sum(yy);
-  if constexpr (BAND) ymax = c.reduce_max(ymax);
+  if constexpr (BAND || kSmoothFast) ymax = c.reduce_max(ymax);
   c.sync();
   double f = refresh_clipped(c, v, r, rc);
   const int ldh = w.ldh;
@@ -540,8 +549,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // (src/cave.py:218) needs rnorm itself resolved, so the gradient test is tightened.
     const double tol_it = (f < 1e-8 * yy) ? 1e-4 * tol : tol;
     if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy) { converged = true; break; }
-    if constexpr (BAND) {
-      // Large-cone path: SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
+    if constexpr (BAND || kSmoothFast) {
+      // SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
       // the CHKS smoothing of the one-sided clip at scale mu (1/2 at the kink, -> the 0/1 activity D_kk
       // as mu -> 0); mu shrinks tenfold per iteration from 0.1*max|y| but stays above 0.03*max|y| times
       // the relative projected gradient, so it vanishes with the error (superlinear end game) while
@@ -574,10 +583,15 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           double v1, v2;
           csc_entry<PM1>(v, e1, a, v1);
           const double va = wk * v1;
-          c.atomic_add_f64(&w.H[a * ldh], va * v1);
+          if constexpr (BAND) c.atomic_add_f64(&w.H[a * ldh], va * v1);
+          else c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
           for (uint32_t e2 = lo; e2 < e1; ++e2) {
             csc_entry<PM1>(v, e2, b, v2);
-            c.atomic_add_f64(&w.H[b * ldh + (a - b)], va * v2);  // columns are sorted: b < a
+            if constexpr (BAND) c.atomic_add_f64(&w.H[b * ldh + (a - b)], va * v2);  // columns are sorted: b < a
+            else {
+              c.atomic_add_f64(&w.H[a * ldh + b], va * v2);
+              c.atomic_add_f64(&w.H[b * ldh + a], va * v2);
+            }
           }
         }
       }
