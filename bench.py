@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--mode", default="inner", choices=["project", "exact", "inner"])
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances timed on the host for cpu_baseline (0=skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip packed-path / train-step side measurements")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side measurements at the instance sizes of BASELINE configs 3-5")
     return ap.parse_args()
 
 
@@ -166,6 +168,8 @@ def main():
         }
         if not args.no_extras:
             res.update(extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs))
+            if not args.no_other_configs and world == 1:
+                res["other_configs"] = other_configs(dev)
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(ctrs_np[ids], pred_np, args.cpu_sample)
         print(json.dumps(res))
@@ -260,6 +264,50 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
         out["train_step_graph_loss"] = float(gl.detach())
     except Exception as e:  # noqa: BLE001 - graph capture is an optional extra
         out["train_step_graph_error"] = repr(e)[:200]
+    return out
+
+
+def other_configs(dev):
+    """Side measurements (not `value`): one GPU's share of BASELINE configs 3-5 on the packed store.
+    A few unique synthetic cones per size (the dense form of TSP-100 is 102 MB per instance) are
+    replicated to the per-GPU batch with independent predictions."""
+    import torch
+
+    from cave_amd import _lib, synth
+    from cave_amd.dataset import ConeStore
+
+    def run(name, gen, n_unique, B, mode, chunk):
+        ctrs, costs, _ = gen(n_unique)
+        c = torch.tensor(ctrs, device=dev)
+        store = ConeStore.from_dense(c, chunk=chunk)
+        del c
+        ids = torch.arange(B, device=dev) % n_unique
+        g = torch.Generator(device="cpu").manual_seed(1)
+        pred = torch.tensor(costs, device=dev)[ids] + 0.05 * torch.randn(B, costs.shape[1], generator=g).to(dev)
+        outs = ("loss", "grad")
+        o = store.cone_op(ids, pred, mode, -1.0, 0.2, outputs=outs)
+        torch.cuda.synchronize()
+        K = 5
+        t0 = time.perf_counter()
+        for _ in range(K):
+            store.cone_op(ids, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        return {"workload": name, "batch_per_gpu": B, "unique_cones": n_unique, "d": int(costs.shape[1]),
+                "reduced_rows_max": store.max_rows, "path": "large (band LDL^T, global workspace)" if store.large else "fast (LDS)",
+                "projections_per_s": B / dt, "ms_per_step": 1e3 * dt, "newton_iters_mean": float(o["iters"].float().mean()),
+                "newton_iters_max": int(o["iters"].max())}
+
+    out = []
+    try:
+        out.append(run("configs[2] TSP-50, CaVE Exact, 4096/8 GPUs", lambda n: synth.tsp_batch(50, n, seed=0), 32, 512,
+                       _lib.MODE_EXACT, 32))
+        out.append(run("configs[3] TSP-100, QP branch of CaVE Hybrid (inner_ratio 0.2), 2048/4 GPUs",
+                       lambda n: synth.tsp_batch(100, n, seed=0), 8, 512, _lib.MODE_INNER, 4))
+        out.append(run("configs[4] shortest path 30x30, CaVE+ (inner), 8192/8 GPUs",
+                       lambda n: synth.sp_batch(30, 30, n, seed=0), 32, 1024, _lib.MODE_INNER, 32))
+    except Exception as e:  # noqa: BLE001 - side measurement only
+        out.append({"error": repr(e)[:300]})
     return out
 
 
