@@ -54,6 +54,9 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   const int ld = bw + 1;
   if (p <= 0) return;
   CAVE_T0();
+  // `c` lives in memory here (a real call): read its fields once, the LDS-only barriers below are
+  // compiler memory barriers and would otherwise reload them from scratch on every pivot
+  const int tid = c.tid(), lane = c.lane_id(), wave = c.wave_id();
   auto Hb = space_cast<GS>(Hb_);
   auto fac = space_cast<GS>(fac_);
   auto act = space_cast<HS>(act_);
@@ -63,7 +66,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   auto stg = space_cast<HS>(stg_);
   double md = 0.0;
   uint32_t nfix = 0;
-  for (int i = c.tid(); i < p; i += NT) {
+  for (int i = tid; i < p; i += NT) {
     if (!act[i]) md = fmax(md, Hb[i * ld]);
     else nfix++;
   }
@@ -71,7 +74,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   nfix = c.reduce_add_u32(nfix);
   const double reg = reg_rel * md;
   // right-hand side: fixed rows keep theirs, free rows move the fixed unknowns over
-  for (int i = c.tid(); i < p; i += NT) {
+  for (int i = tid; i < p; i += NT) {
     double zi = rhs[i];
     if (nfix != 0u && !act[i]) {
       const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
@@ -81,7 +84,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     z[i] = zi;
   }
   if (bw == 0) {  // diagonal system
-    for (int i = c.tid(); i < p; i += NT) {
+    for (int i = tid; i < p; i += NT) {
       const double dk = act[i] ? 1.0 : Hb[i] + reg;
       x[i] = (dk > 1e-300) ? z[i] / dk : 0.0;
     }
@@ -94,20 +97,22 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   auto fetch = [&](decltype(Hb) src, int e0, int eend) {
 #pragma unroll
     for (int j = 0; j < RMAX; ++j) {
-      const int idx = c.tid() + j * NT;
-      if (idx < csz) regs[j] = (e0 + idx < eend) ? src[e0 + idx] : 0.0;
+      // unconditional load from a clamped index: a select around the load would make each load wait
+      // for the previous one (entries past the range are parked but never read)
+      const int e = e0 + tid + j * NT;
+      regs[j] = src[e < eend ? e : eend - 1];
     }
   };
   auto fetch_h = [&](int r0) { fetch(Hb, r0 * ld, p * ld); };  // raw rows r0 .. r0+CH-1 of H (masked on insertion)
   auto park = [&](int b) {
 #pragma unroll
     for (int j = 0; j < RMAX; ++j) {
-      const int idx = c.tid() + j * NT;
+      const int idx = tid + j * NT;
       if (idx < csz) stg[b * csz + idx] = regs[j];
     }
   };
   // ring window: band row r lives in slot r % ld; rows ld .. p-1 arrive through the staging buffers
-  for (int idx = c.tid(); idx < ld * ld; idx += NT) {
+  for (int idx = tid; idx < ld * ld; idx += NT) {
     const int r = idx / ld, t = idx - r * ld;
     win[idx] = band_row_entry(Hb, ld, act, p, reg, r, t);
   }
@@ -124,54 +129,113 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   double inv_prev = 0.0;
   c.sync();
   CAVE_ACC(10);
+  int nb_cached = -1, na_cached = -1, qn = 0, rn = 0, s_first = 0, t_first = 0, s_rest = 0, t_rest = 0;
+  constexpr int U = 4;
+  int ua[U], ub[U], ur[U];
+  bool uok[U];
   int slot_k = 0;          // k % ld, kept incrementally
   int cpos = 0, cidx = 0;  // position of the row inserted at this step inside its chunk, chunk index
+  // The body of a step is written load / compute / store: every LDS operand of the step (pivot, the first
+  // U triangle pairs of this thread, its z entry, the retiring and the entering row entry) is requested
+  // before the reciprocal pivot is formed, so the step costs about one LDS round trip plus the division
+  // instead of one round trip per statement.  Remainders (wide bands) take the plain loops below.
   for (int k = 0; k < p; ++k) {
     auto wk = win + slot_k * ld;
-    const double dk = wk[0];
-    const bool ok = dk > 1e-300;
-    const double inv = ok ? 1.0 / dk : 0.0;
     const int nb = bw < p - 1 - k ? bw : p - 1 - k;
     // rows updated by phase A: s = 1 .. na (row k+bw is phase B's, except at k = 0 where it is already resident)
     const int na = (k == 0 || nb < bw) ? nb : bw - 1;
-    const double zk = z[k];
-    if (na > 0) {
-      // upper triangle s <= t of the na x nb block, flat index walked without per-element division
-      const int qn = NT / nb, rn = NT - qn * nb;
-      int s0 = c.tid() / nb, t0 = c.tid() - s0 * nb;
-      while (s0 < na) {
-        if (t0 >= s0) {
-          const int sft = s0 + 1, tt = t0 + 1;
-          int slot = slot_k + sft;
-          if (slot >= ld) slot -= ld;
-          auto row = win + slot * ld;
-          row[tt - sft] -= wk[sft] * inv * wk[tt];
-        }
-        s0 += qn;
-        t0 += rn;
-        if (t0 >= nb) { t0 -= nb; ++s0; }
+    if (nb != nb_cached || na != na_cached) {  // only at the start and in the last bw steps
+      nb_cached = nb; na_cached = na;
+      if (nb > 0) {
+        qn = NT / nb; rn = NT - qn * nb;
+        s_first = tid / nb; t_first = tid - s_first * nb;
       }
+      // this thread's first U pairs of the triangle: operand offsets relative to the pivot row's slot
+      int s0 = s_first, t0 = t_first;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uok[u] = (na > 0) && (s0 < na) && (t0 >= s0);
+        const int sc = uok[u] ? s0 : 0, tc = uok[u] ? t0 : 0;  // clamped: loads are unconditional
+        ua[u] = sc + 1;
+        ub[u] = tc + 1;
+        ur[u] = (sc + 1) * ld + (tc - sc);
+        if (nb > 0) {
+          s0 += qn;
+          t0 += rn;
+          if (t0 >= nb) { t0 -= nb; ++s0; }
+        }
+      }
+      s_rest = s0; t_rest = t0;
     }
-    for (int s = 1 + c.tid(); s <= nb; s += NT) z[k + s] -= wk[s] * inv * zk;
-    if (k > 0) {
-      auto wp = win + (slot_k == 0 ? bw : slot_k - 1) * ld;
-      const bool ins = streaming && (k - 1 + ld < p);
-      if (ins && cpos == 0) {
-        // first row of chunk cidx: chunk cidx+1 (in registers) takes the buffer chunk cidx-1 has just left
-        park((cidx + 1) & 1);
-        fetch_h(ld + (cidx + 2) * CH);
+    // ---- loads
+    const int base_k = slot_k * ld;
+    const double dk = wk[0];
+    const double zk = z[k];
+    const double wbw = wk[bw];
+    double pa[U], pb[U], pr[U];
+    int poff[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int o = base_k + ur[u];
+      if (o >= ld * ld) o -= ld * ld;
+      poff[u] = o;
+      pa[u] = wk[ua[u]];
+      pb[u] = wk[ub[u]];
+      pr[u] = win[o];
+    }
+    int s0 = s_rest, t0 = t_rest;
+    const bool zown = 1 + tid <= nb;
+    const double zw = wk[zown ? 1 + tid : 0];
+    const double zz = z[zown ? k + 1 + tid : k];
+    const bool retire = k > 0;
+    const bool ins = retire && streaming && (k - 1 + ld < p);
+    auto wp = win + (slot_k == 0 ? bw : slot_k - 1) * ld;
+    if (ins && cpos == 0) {
+      // first row of chunk cidx: chunk cidx+1 (in registers) takes the buffer chunk cidx-1 has just left
+      park((cidx + 1) & 1);
+      fetch_h(ld + (cidx + 2) * CH);
+    }
+    auto src = stg + (cidx & 1) * csz + cpos * ld;
+    // row rI = k + bw of H as the elimination sees it (band_row_entry on the staged raw row)
+    auto entering = [&](int t) -> double {
+      const int rI = k + bw, i = rI + t;
+      if (!ins || i >= p) return 0.0;
+      const double raw = src[t];
+      return (t == 0) ? (act[rI] ? 1.0 : raw + reg) : ((act[rI] || act[i]) ? 0.0 : raw);
+    };
+    const bool town = retire && tid <= bw;
+    const double rold = town ? wp[tid] : 0.0;
+    double rnew = town ? entering(tid) : 0.0;
+    // ---- compute
+    const bool ok = dk > 1e-300;
+    const double inv = ok ? 1.0 / dk : 0.0;
+    // ---- stores
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (uok[u]) win[poff[u]] = pr[u] - pa[u] * inv * pb[u];
+    while (s0 < na) {  // pairs beyond the first U per thread
+      if (t0 >= s0) {
+        const int sft = s0 + 1, tt = t0 + 1;
+        int slot = slot_k + sft;
+        if (slot >= ld) slot -= ld;
+        auto row = win + slot * ld;
+        row[tt - sft] -= wk[sft] * inv * wk[tt];
       }
-      auto src = stg + (cidx & 1) * csz + cpos * ld;
-      for (int t = c.tid(); t <= bw; t += NT) {
-        fac[(k - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
-        double nv = 0.0;
-        if (ins) {  // row rI = k + bw of H as the elimination sees it (band_row_entry on the staged raw row)
-          const int rI = k + bw, i = rI + t;
-          const double raw = src[t];
-          if (i < p) nv = (t == 0) ? (act[rI] ? 1.0 : raw + reg) : ((act[rI] || act[i]) ? 0.0 : raw);
-        }
-        if (t == 0 && k + bw < p) nv -= wk[bw] * inv * wk[bw];
-        wp[t] = nv;
+      s0 += qn;
+      t0 += rn;
+      if (t0 >= nb) { t0 -= nb; ++s0; }
+    }
+    if (zown) z[k + 1 + tid] = zz - zw * inv * zk;
+    for (int sx = 1 + tid + NT; sx <= nb; sx += NT) z[k + sx] -= wk[sx] * inv * zk;
+    if (retire) {
+      if (town) {
+        fac[(k - 1) * ld + tid] = (tid == 0) ? inv_prev : rold;
+        if (tid == 0 && k + bw < p) rnew -= wbw * inv * wbw;
+        wp[tid] = rnew;
+      }
+      for (int t = tid + NT; t <= bw; t += NT) {
+        fac[(k - 1) * ld + t] = wp[t];
+        wp[t] = entering(t);
       }
       if (ins && ++cpos == CH) { cpos = 0; ++cidx; }
     }
@@ -182,7 +246,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   }
   {
     auto wp = win + ((p - 1) % ld) * ld;
-    for (int t = c.tid(); t <= bw; t += NT) fac[(p - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
+    for (int t = tid; t <= bw; t += NT) fac[(p - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
   }
   c.sync();  // full barrier: the factor rows are in (workgroup-visible) global memory now
   CAVE_ACC(11);
@@ -200,9 +264,8 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     if (khi - CH >= 0) fetch_f(khi - CH);
     if constexpr (HOT) c.sync_lds();
     else c.sync();
-    if (c.wave_id() == 0) {
+    if (wave == 0) {
       constexpr int WL = C::WL;
-      const int lane = c.lane_id();
       const int klo = khi - CH + 1 > 0 ? khi - CH + 1 : 0;
       for (int k = khi; k >= klo; --k) {
         auto fk = stg + b * csz + (k - klo) * ld;

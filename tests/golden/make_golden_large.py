@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Generate tests/golden/large.npz: reference outputs (solver='nnls') for cones beyond the LDS-resident
 solver — 12x12 and 30x30 grid shortest-path cones (SciPy needs about a minute per 30x30 instance) and,
-with --tsp100, one TSP-100 instance.  Inputs are regenerated from the seeds by cave_amd.synth.
+with --tsp100, one TSP-100 instance (26 minutes in SciPy; the committed large.npz was made with it).  Inputs are regenerated from the seeds by cave_amd.synth.
 
     python tests/golden/make_golden_large.py [--tsp100]
 

@@ -258,12 +258,13 @@ def test_large_path_dense_generators_vs_oracle(hip):
 
 
 def test_large_path_reference_fixture(hip, golden):
-    """12x12 and 30x30 grid shortest-path cones against the reference's own outputs (tests/golden/large.npz)."""
+    """12x12 / 30x30 grid shortest-path cones and one TSP-100 cone against the reference's own outputs
+    (tests/golden/large.npz; SciPy needed 44 s for the 30x30 instance and 26 min for the TSP-100 one)."""
     from cave_amd import synth
 
     g = golden["large"]
-    for tag, (h, n) in (("sp12", (12, 4)), ("sp30", (30, 1))):
-        c, y, _ = synth.sp_batch(h, h, n, seed=0)
+    for tag, (h, n) in (("sp12", (12, 4)), ("sp30", (30, 1)), ("tsp100", (100, 1))):
+        c, y, _ = synth.tsp_batch(h, n, seed=0) if tag == "tsp100" else synth.sp_batch(h, h, n, seed=0)
         o = hip(c, y, MODE_PROJECT, -1.0, 0.0)
         assert (o["status"] == 0).all() and o["iters"].max() <= 20
         ok = g[f"{tag}_consistent"]

@@ -42,8 +42,8 @@ def test_large_path_code_vs_reference_fixture(emul, golden):
     from cave_amd import synth
 
     g = golden["large"]
-    for tag, (h, n) in (("sp12", (12, 4)), ("sp30", (30, 1))):
-        c, y, _ = synth.sp_batch(h, h, n, seed=0)
+    for tag, (h, n) in (("sp12", (12, 4)), ("sp30", (30, 1)), ("tsp100", (100, 1))):
+        c, y, _ = synth.tsp_batch(h, n, seed=0) if tag == "tsp100" else synth.sp_batch(h, h, n, seed=0)
         o = emul.cone_dense_large(c, y, MODE_PROJECT, sign=-1.0)
         assert (o["status"] == 0).all() and o["iters"].max() <= 20
         ok = g[f"{tag}_consistent"]
