@@ -15,7 +15,7 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 kern = sys.argv[3] if len(sys.argv) > 3 else "cone_dense_kernel"
 out = {"kernel": kern}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    fs = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    fs = sorted(glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not fs:
         continue
     acc = {}
@@ -25,7 +25,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for k, v in acc.items():
         out[k] = sum(v) / len(v)
         out[k + "_launches"] = len(v)
-fs = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+fs = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if fs:
     for r in csv.DictReader(open(fs[0])):
         if kern in r["Name"]:
