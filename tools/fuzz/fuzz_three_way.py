@@ -1,6 +1,6 @@
 """Three-way fuzz (CPU): serial build of the kernel code vs the Lawson-Hanson oracle vs SciPy nnls on
 adversarial random cones (duplicates, +-pairs, unit rows, rank deficiency, points inside / on faces).
-    python tools/fuzz/fuzz_three_way.py [seed] [seconds]
+    python tools/fuzz/fuzz_three_way.py [seed] [seconds] [large]     (large: the large-cone path's code)
 Used during round 1: 900k instances, 0 silent mismatches of the kernel code vs the oracle,
 ~0.5 % SciPy 1.15.3 answers that disagree with both."""
 import sys, time
@@ -14,6 +14,7 @@ from scipy.optimize import nnls
 E = Emul()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 0)
 T = float(sys.argv[2]) if len(sys.argv)>2 else 60
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
 n=0; bad_ours=0; bad_scipy=0; scipy_err=0; worst=0; itmax=0; by_kind={}
 t0=time.time()
 def kkt_gap(A, y, p):
@@ -45,7 +46,8 @@ while time.time()-t0 < T:
     if kind == 5 and m > 0:
         lam = rng.random((B, m)).astype(np.float32); y = np.einsum("bm,bmd->bd", lam, A)
     if rng.random() < 0.1: y[:] = 0
-    o = E.cone_dense(A, y, 0, sign=1.0, nnz_cap=max(m*d,64), lds_bytes=160*1024)
+    if LARGE: o = E.cone_dense_large(A, y, 0, sign=1.0, nnz_cap=max(m*d,64), band=max(m*m,1), lds_bytes=int(rng.choice([1024, 8192, 65536])))
+    else: o = E.cone_dense(A, y, 0, sign=1.0, nnz_cap=max(m*d,64), lds_bytes=160*1024)
     po, ro = O.batch_project(y, A)
     for b in range(B):
         n+=1
