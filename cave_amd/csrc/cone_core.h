@@ -54,15 +54,6 @@ struct ConeBuild {
   int n_valid_avg;
 };
 
-// Smoothed generalised Hessian (see solve_cone_impl) on the LDS-resident fast path too?  Measured on
-// TSP-20: the iteration count tightens (max 10 -> 8 over 512 instances, mean unchanged) but rebuilding H
-// every iteration costs more than the incremental +-1 updates save: 238 -> 248 us at B = 1024 and
-// 333 -> 584 us at B = 4096 (packed).  Off; the large-cone path, where it is 10x fewer iterations, has it.
-#ifndef CAVE_SMOOTH_FAST
-#define CAVE_SMOOTH_FAST 0
-#endif
-static constexpr bool kSmoothFast = CAVE_SMOOTH_FAST != 0;
-
 static constexpr uint32_t kHashPrefix = 12;
 static constexpr uint32_t kLongRow = 64;   // rows longer than this are handled by the whole team, one at a time
 static constexpr uint8_t ROW_PM1 = 0x20;   // every entry of the row is +-1
@@ -515,15 +506,15 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   for (int k = c.tid(); k < d; k += NT) {
     yy += (double)w.y[k] * (double)w.y[k];
     r[k] = (double)w.y[k];
-    if constexpr (BAND || kSmoothFast) ymax = fmax(ymax, fabs((double)w.y[k]));
+    ymax = fmax(ymax, fabs((double)w.y[k]));
   }
   yy = c.reduce_sum(yy);
-  if constexpr (BAND || kSmoothFast) ymax = c.reduce_max(ymax);
+  ymax = c.reduce_max(ymax);
   c.sync();
   double f = refresh_clipped(c, v, r, rc);
   const int ldh = w.ldh;
   for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
-  for (int k = c.tid(); k < d; k += NT) w.dflag[k] = 0;
+  if constexpr (!BAND) for (int k = c.tid(); k < d; k += NT) w.wold[k] = 0.f;
   c.sync();
   double g0n = 0.0;
   double reg_rel = 1e-10;  // Levenberg shift relative to max diag(H); raised when a step stalls
@@ -549,7 +540,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // (src/cave.py:218) needs rnorm itself resolved, so the gradient test is tightened.
     const double tol_it = (f < 1e-8 * yy) ? 1e-4 * tol : tol;
     if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy) { converged = true; break; }
-    if constexpr (BAND || kSmoothFast) {
+    if constexpr (BAND) {
       // SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
       // the CHKS smoothing of the one-sided clip at scale mu (1/2 at the kink, -> the 0/1 activity D_kk
       // as mu -> 0); mu shrinks tenfold per iteration from 0.1*max|y| but stays above 0.03*max|y| times
@@ -596,25 +587,44 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         }
       }
     } else {
-    // generalised Hessian H = M D M^T, D = [Pi(r) != 0]: rank-one updates +-m_k m_k^T for the
-    // coordinates whose activity flipped since the previous iteration (all active ones at it 0)
-    for (int k = c.tid(); k < d; k += NT) {
-      const uint8_t on = (uint8_t)active_unit(r[k], v.usign[k]);
-      if (on == w.dflag[k]) continue;
-      w.dflag[k] = on;
-      const double sg = on ? 1.0 : -1.0;
-      uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
-      for (uint32_t e1 = lo; e1 < hi; ++e1) {
-        uint32_t a, b;
-        double v1, v2;
-        csc_entry<PM1>(v, e1, a, v1);
-        const double va = sg * v1;
-        c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
-        for (uint32_t e2 = lo; e2 < e1; ++e2) {
-          csc_entry<PM1>(v, e2, b, v2);
-          double vv = va * v2;
-          c.atomic_add_f64(&w.H[a * ldh + b], vv);
-          c.atomic_add_f64(&w.H[b * ldh + a], vv);
+    // generalised Hessian H = M W M^T, kept incrementally: H += (w_k - w_k_old) m_k m_k^T for the coordinates
+    // whose weight changed.  Far from its kink a coordinate has the 0/1 activity D_kk = [Pi(r)_k != 0]; within
+    // 8 mu of it the weight is the CHKS-smoothed step quantised to 1/64, mu = 0.1 max|y| * (relative projected
+    // gradient).  So mu -> 0 with the error (the end game is the plain semismooth Newton method), few
+    // coordinates are ever fractional, and a coordinate resting on its kink keeps weight 1/2 instead of
+    // flipping the active set every iteration (SP 5x5: 6.6 -> 3.9 iterations on average, worst 21 -> 7;
+    // TSP-20: 5.87 -> 5.75, instances needing >= 8 iterations 52 -> 8 of 1024).
+    {
+      const double mu = 0.1 * ymax * (pgn / g0n);
+      const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
+      for (int k = c.tid(); k < d; k += NT) {
+        const uint8_t u = v.usign[k];
+        float wn;
+        if (u == 0) wn = 1.0f;
+        else if (u == 3) wn = 0.0f;
+        else {
+          const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
+          const double z = t * inv_mu;
+          if (mu > 0.0 && fabs(z) < 8.0) wn = (float)(floor(32.0 * (1.0 + z / sqrt(1.0 + z * z)) + 0.5) * (1.0 / 64.0));
+          else wn = t > 0.0 ? 1.0f : 0.0f;
+        }
+        const float wo = w.wold[k];
+        if (wn == wo) continue;
+        w.wold[k] = wn;
+        const double dw = (double)wn - (double)wo;
+        uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
+        for (uint32_t e1 = lo; e1 < hi; ++e1) {
+          uint32_t a, b;
+          double v1, v2;
+          csc_entry<PM1>(v, e1, a, v1);
+          const double va = dw * v1;
+          c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
+          for (uint32_t e2 = lo; e2 < e1; ++e2) {
+            csc_entry<PM1>(v, e2, b, v2);
+            double vv = va * v2;
+            c.atomic_add_f64(&w.H[a * ldh + b], vv);
+            c.atomic_add_f64(&w.H[b * ldh + a], vv);
+          }
         }
       }
     }

@@ -182,7 +182,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.rc = hot_get<double>(hot, ar, d);
       res = hot_get<double>(hot, ar, d);
       tvec = hot_get<double>(hot, ar, d);
-      w.dflag = hot_get<uint8_t>(hot, ar, d);
+      w.wold = nullptr;
       w.H = ar.get<double>(pp * ld);
       w.bfac = ar.get<double>(pp * ld);
 #if defined(__HIPCC__)
@@ -192,7 +192,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     } else {
       if (p > C::PMAX) return ST_TOO_LARGE;
       w.rc = ar.get<double>(d);
-      w.dflag = ar.get<uint8_t>(d);
+      w.wold = ar.get<float>(d);
       w.theta = ar.get<double>(pp);
       w.ttry = ar.get<double>(pp);
       w.g = ar.get<double>(pp);
@@ -214,7 +214,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
     vv.longrow = llist;
     c.sync();
-    SolveResult r = solve_cone<C, LARGE>(c, vv, w, max_iter, 1e-10);
+    SolveResult r = solve_cone<C, LARGE>(c, vv, w, max_iter, 1e-11);
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
@@ -462,7 +462,7 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
                    + 3 * align8u(4 * rows_raw) + align8u(rows_raw) + align8u(2 * m)               // vraw, vnorm, twin, keep, rowvar
                    + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // signatures | fill
   uint64_t vecs = 2 * align8u(4 * d);                                                            // y, avg
-  uint64_t solve = 3 * align8u(8 * d) + align8u(d)                                               // res, tvec/q, rc, dflag
+  uint64_t solve = 3 * align8u(8 * d) + align8u(4 * d)                                           // res, tvec/q, rc, wold
                    + 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, H, act, long rows
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
@@ -528,7 +528,7 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
   s += align8u(4 * (p + 1)) + align8u(p);                                               // mptr, vkind
   s += 2 * (align8u(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : align8u(4 * (int64_t)max_nnz)));  // CSR + CSC (+ values)
-  s += align8u(8 * d) * 3 + align8u(d);                                                  // res, tvec, rc, dflag
+  s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
   s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
   if (s > kMaxLds) return -1;
   return (int32_t)s;
