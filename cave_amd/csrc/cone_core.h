@@ -589,7 +589,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     } else {
     // generalised Hessian H = M W M^T, kept incrementally: H += (w_k - w_k_old) m_k m_k^T for the coordinates
     // whose weight changed.  Far from its kink a coordinate has the 0/1 activity D_kk = [Pi(r)_k != 0]; within
-    // 8 mu of it the weight is the CHKS-smoothed step quantised to 1/64, mu = 0.1 max|y| * (relative projected
+    // 4 mu of it the weight is the CHKS-smoothed step quantised to 1/16, mu = 0.1 max|y| * (relative projected
     // gradient).  So mu -> 0 with the error (the end game is the plain semismooth Newton method), few
     // coordinates are ever fractional, and a coordinate resting on its kink keeps weight 1/2 instead of
     // flipping the active set every iteration (SP 5x5: 6.6 -> 3.9 iterations on average, worst 21 -> 7;
@@ -604,8 +604,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         else if (u == 3) wn = 0.0f;
         else {
           const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
-          const double z = t * inv_mu;
-          if (mu > 0.0 && fabs(z) < 8.0) wn = (float)(floor(32.0 * (1.0 + z / sqrt(1.0 + z * z)) + 0.5) * (1.0 / 64.0));
+          const float z = (float)(t * inv_mu);  // the weight is a heuristic, quantised anyway: float is plenty
+          if (mu > 0.0 && fabsf(z) < 4.0f) wn = floorf(8.0f * (1.0f + z / sqrtf(1.0f + z * z)) + 0.5f) * (1.0f / 16.0f);
           else wn = t > 0.0 ? 1.0f : 0.0f;
         }
         const float wo = w.wold[k];
