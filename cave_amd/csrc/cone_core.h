@@ -551,40 +551,49 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // iterations on a 30x30 grid), with W it takes 7-10.  The gradient and the line search stay exact,
       // so every step still decreases f and the limit is the same projection.  H is rebuilt per
       // iteration (O(sum of squared column counts) atomics).
-      for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
-      c.sync();
+      // When the whole band fits the (idle) LDS ring window -- dense reduced systems, p <= bw + 1: TSP --
+      // it is accumulated there with LDS atomics and copied out; otherwise straight into the workspace.
+      const bool in_lds = w.band_hot && p <= ldh;
       double mu = (it < 6) ? 0.1 * ymax * pow(0.1, (double)it) : 0.0;
       mu = fmax(mu, 0.03 * ymax * (pgn / g0n));
-      for (int k = c.tid(); k < d; k += NT) {
+      auto weight = [&](int k) -> double {
         const uint8_t u = v.usign[k];
-        double wk;
-        if (u == 0) wk = 1.0;
-        else if (u == 3) wk = 0.0;
-        else {
-          const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
-          if (mu > 0.0) {
-            const double z = t / mu;
-            wk = 0.5 * (1.0 + z / sqrt(1.0 + z * z));
-          } else wk = (t > 0.0) ? 1.0 : 0.0;
+        if (u == 0) return 1.0;
+        if (u == 3) return 0.0;
+        const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
+        if (mu > 0.0) {
+          const double z = t / mu;
+          return 0.5 * (1.0 + z / sqrt(1.0 + z * z));
         }
-        if (!(wk > 1e-14)) continue;
-        uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
-        for (uint32_t e1 = lo; e1 < hi; ++e1) {
-          uint32_t a, b;
-          double v1, v2;
-          csc_entry<PM1>(v, e1, a, v1);
-          const double va = wk * v1;
-          if constexpr (BAND) c.atomic_add_f64(&w.H[a * ldh], va * v1);
-          else c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
-          for (uint32_t e2 = lo; e2 < e1; ++e2) {
-            csc_entry<PM1>(v, e2, b, v2);
-            if constexpr (BAND) c.atomic_add_f64(&w.H[b * ldh + (a - b)], va * v2);  // columns are sorted: b < a
-            else {
-              c.atomic_add_f64(&w.H[a * ldh + b], va * v2);
-              c.atomic_add_f64(&w.H[b * ldh + a], va * v2);
+        return (t > 0.0) ? 1.0 : 0.0;
+      };
+      auto accumulate = [&](auto Hacc, auto add) {
+        for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
+        c.sync();
+        for (int k = c.tid(); k < d; k += NT) {
+          const double wk = weight(k);
+          if (!(wk > 1e-14)) continue;
+          uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
+          for (uint32_t e1 = lo; e1 < hi; ++e1) {
+            uint32_t a, b;
+            double v1, v2;
+            csc_entry<PM1>(v, e1, a, v1);
+            const double va = wk * v1;
+            add(Hacc + a * ldh, va * v1);
+            for (uint32_t e2 = lo; e2 < e1; ++e2) {
+              csc_entry<PM1>(v, e2, b, v2);
+              add(Hacc + (b * ldh + (a - b)), va * v2);  // columns are sorted: b < a
             }
           }
         }
+      };
+      if (in_lds) {
+        auto Hl = space_cast<3>(w.bwin);
+        accumulate(Hl, [&](decltype(Hl) q, double x) { c.atomic_add_f64_lds(q, x); });
+        c.sync();
+        for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = Hl[idx];
+      } else {
+        accumulate(w.H, [&](double* q, double x) { c.atomic_add_f64(q, x); });
       }
     } else {
     // generalised Hessian H = M W M^T, kept incrementally: H += (w_k - w_k_old) m_k m_k^T for the coordinates

@@ -108,6 +108,9 @@ struct BlockCtx {
   __device__ __forceinline__ void atomic_add_u32(uint32_t* p, uint32_t v) const { atomicAdd(p, v); }
   __device__ __forceinline__ uint32_t atomic_inc_ret_u32(uint32_t* p) const { return atomicAdd(p, 1u); }
   __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }
+  __device__ __forceinline__ void atomic_add_f64_lds(typename SpacePtr<double, 3>::type p, double v) const {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f64
+  }
 
   // publish this wave's count, return (sum over lower waves, total)
   __device__ __forceinline__ void wave_prefix(uint32_t wcount, uint32_t& pre, uint32_t& tot) {
