@@ -215,6 +215,9 @@ def test_training_example_reduces_regret():
         hist = train_sp_cave.main(["--epochs", "6", "--num-data", "100", "--batch", "32"] + extra)
         assert hist[-1][2] < 0.6 * hist[0][2], hist          # regret drops
         assert hist[-1][1] < hist[1][1], hist                # loss drops
+    # BASELINE configs[4] grid size through the large-cone path (900 reduced rows per instance)
+    hist = train_sp_cave.main(["--grid", "30", "30", "--epochs", "3", "--num-data", "96", "--batch", "32", "--packed"])
+    assert hist[-1][2] < 0.9 * hist[0][2] and hist[-1][1] < hist[1][1], hist
 
 
 # ------------------------------------------------------------------ large-cone path (BASELINE configs 4 and 5)
