@@ -30,6 +30,9 @@ CAVE_HD double band_row_entry(PH Hb, int ld, PA act, int p, double reg, int r, i
   return fixed ? 0.0 : Hb[r * ld + t];
 }
 
+struct TrueTag { static constexpr bool value = true; };
+struct FalseTag { static constexpr bool value = false; };
+
 // rows staged per chunk (see solve_spd_band): bounded by the per-thread prefetch registers
 template <class C>
 CAVE_HD int band_chunk_rows(int ld) {
@@ -139,12 +142,15 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   // U triangle pairs of this thread, its z entry, the retiring and the entering row entry) is requested
   // before the reciprocal pivot is formed, so the step costs about one LDS round trip plus the division
   // instead of one round trip per statement.  Remainders (wide bands) take the plain loops below.
-  for (int k = 0; k < p; ++k) {
+  auto step = [&](const int k, auto steady_tag) {
+    // STEADY: 2 <= k, k + 2 bw < p, not the first row of a staged chunk -- the band is full width, a row
+    // retires and a row enters, nothing is recomputed or fetched: the common case, kept branch-light
+    constexpr bool STEADY = decltype(steady_tag)::value;
     auto wk = win + slot_k * ld;
-    const int nb = bw < p - 1 - k ? bw : p - 1 - k;
+    const int nb = STEADY ? bw : (bw < p - 1 - k ? bw : p - 1 - k);
     // rows updated by phase A: s = 1 .. na (row k+bw is phase B's, except at k = 0 where it is already resident)
-    const int na = (k == 0 || nb < bw) ? nb : bw - 1;
-    if (nb != nb_cached || na != na_cached) {  // only at the start and in the last bw steps
+    const int na = STEADY ? bw - 1 : ((k == 0 || nb < bw) ? nb : bw - 1);
+    if (!STEADY && (nb != nb_cached || na != na_cached)) {  // only at the start and in the last bw steps
       nb_cached = nb; na_cached = na;
       if (nb > 0) {
         qn = NT / nb; rn = NT - qn * nb;
@@ -187,10 +193,10 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     const bool zown = 1 + tid <= nb;
     const double zw = wk[zown ? 1 + tid : 0];
     const double zz = z[zown ? k + 1 + tid : k];
-    const bool retire = k > 0;
-    const bool ins = retire && streaming && (k - 1 + ld < p);
+    const bool retire = STEADY || k > 0;
+    const bool ins = STEADY || (retire && streaming && (k - 1 + ld < p));
     auto wp = win + (slot_k == 0 ? bw : slot_k - 1) * ld;
-    if (ins && cpos == 0) {
+    if (!STEADY && ins && cpos == 0) {
       // first row of chunk cidx: chunk cidx+1 (in registers) takes the buffer chunk cidx-1 has just left
       park((cidx + 1) & 1);
       fetch_h(ld + (cidx + 2) * CH);
@@ -199,7 +205,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     // row rI = k + bw of H as the elimination sees it (band_row_entry on the staged raw row)
     auto entering = [&](int t) -> double {
       const int rI = k + bw, i = rI + t;
-      if (!ins || i >= p) return 0.0;
+      if (!STEADY && (!ins || i >= p)) return 0.0;
       const double raw = src[t];
       return (t == 0) ? (act[rI] ? 1.0 : raw + reg) : ((act[rI] || act[i]) ? 0.0 : raw);
     };
@@ -230,7 +236,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     if (retire) {
       if (town) {
         fac[(k - 1) * ld + tid] = (tid == 0) ? inv_prev : rold;
-        if (tid == 0 && k + bw < p) rnew -= wbw * inv * wbw;
+        if (tid == 0 && (STEADY || k + bw < p)) rnew -= wbw * inv * wbw;
         wp[tid] = rnew;
       }
       for (int t = tid + NT; t <= bw; t += NT) {
@@ -243,6 +249,16 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     if (++slot_k == ld) slot_k = 0;
     if constexpr (HOT) c.sync_lds();
     else c.sync();
+  };
+  for (int k = 0; k < p;) {
+    if (streaming && k >= 2 && k + 2 * bw < p && cpos != 0) {
+      int kend = k + (CH - cpos);  // up to the end of the staged chunk
+      if (kend > p - 2 * bw) kend = p - 2 * bw;
+      for (; k < kend; ++k) step(k, TrueTag{});
+    } else {
+      step(k, FalseTag{});
+      ++k;
+    }
   }
   {
     auto wp = win + ((p - 1) % ld) * ld;
@@ -259,12 +275,33 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   };
   fetch_f(p - 1);
   int b = 0;
+  double xw = 0.0;  // register window of the narrow-band back substitution
   for (int khi = p - 1; khi >= 0; khi -= CH, b ^= 1) {
     park(b);
     if (khi - CH >= 0) fetch_f(khi - CH);
     if constexpr (HOT) c.sync_lds();
     else c.sync();
-    if (wave == 0) {
+    if (wave == 0 && C::WL > 1 && bw < C::WL) {
+      // narrow band: the window x_{k+1} .. x_{k+bw} lives in registers (lane s-1 holds x_{k+s}) and moves up
+      // one lane per row, so the loop-carried chain is one wave reduction, not an LDS round trip
+      const int klo = khi - CH + 1 > 0 ? khi - CH + 1 : 0;
+      if (khi == p - 1) xw = 0.0;
+      int k = khi;
+      // two rows' factor entries in flight
+      auto row_entry = [&](int kk) -> double { return (kk >= klo && lane < bw) ? stg[b * csz + (kk - klo) * ld + 1 + lane] : 0.0; };
+      double fnext = row_entry(k);
+      for (; k >= klo; --k) {
+        const double fcur = fnext;
+        fnext = row_entry(k - 1);
+        const double f0 = stg[b * csz + (k - klo) * ld];
+        const double zk = z[k];
+        const double part = c.wave_sum(fcur * xw);  // entries past the matrix end multiply x = 0
+        const double xk = f0 * (zk - part);
+        if (lane == 0) x[k] = xk;
+        xw = c.wave_shift_up(xw);
+        if (lane == 0) xw = xk;
+      }
+    } else if (wave == 0) {
       constexpr int WL = C::WL;
       const int klo = khi - CH + 1 > 0 ? khi - CH + 1 : 0;
       for (int k = khi; k >= klo; --k) {

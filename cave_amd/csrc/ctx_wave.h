@@ -29,6 +29,8 @@ struct WaveCtx {
   // sum / max over the lanes of the calling wave only (no barrier; every lane gets the result)
   __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
   __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
+  // lane l gets lane l-1's value (lane 0: 0)
+  __device__ __forceinline__ double wave_shift_up(double v) const { return dpp_f64<0x138, 0xf>(0.0, v); }  // wave_shr:1
   // barrier that orders LDS traffic only (typed ds_* accesses): does not wait for global loads / stores in flight
   __device__ __forceinline__ void sync_lds() const {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

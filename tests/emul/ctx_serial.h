@@ -24,6 +24,7 @@ struct SerialCtx {
   int lane_id() const { return 0; }
   double wave_sum(double v) const { return v; }
   double wave_max(double v) const { return v; }
+  double wave_shift_up(double) const { return 0.0; }
   void wave_fence() const {}
   void wave_fence_lds() const {}
   void sync_lds() const {}
