@@ -136,13 +136,16 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   constexpr int U = 4;
   int ua[U], ub[U], ur[U];
   bool uok[U];
+  const bool narrow = bw < NT && bw * (bw - 1) <= U * NT;  // every pair, z entry and row entry has its own thread
   int slot_k = 0;          // k % ld, kept incrementally
   int cpos = 0, cidx = 0;  // position of the row inserted at this step inside its chunk, chunk index
   // The body of a step is written load / compute / store: every LDS operand of the step (pivot, the first
   // U triangle pairs of this thread, its z entry, the retiring and the entering row entry) is requested
   // before the reciprocal pivot is formed, so the step costs about one LDS round trip plus the division
   // instead of one round trip per statement.  Remainders (wide bands) take the plain loops below.
-  auto step = [&](const int k, auto steady_tag) {
+  auto step = [&](const int k, auto steady_tag, auto narrow_tag) __attribute__((always_inline)) {
+    // NARROW: bw < NT and the whole triangle fits the U pairs per thread -- no remainder loops at all
+    constexpr bool NARROW = decltype(narrow_tag)::value;
     // STEADY: 2 <= k, k + 2 bw < p, not the first row of a staged chunk -- the band is full width, a row
     // retires and a row enters, nothing is recomputed or fetched: the common case, kept branch-light
     constexpr bool STEADY = decltype(steady_tag)::value;
@@ -219,6 +222,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (uok[u]) win[poff[u]] = pr[u] - pa[u] * inv * pb[u];
+    if constexpr (!NARROW)
     while (s0 < na) {  // pairs beyond the first U per thread
       if (t0 >= s0) {
         const int sft = s0 + 1, tt = t0 + 1;
@@ -232,17 +236,19 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
       if (t0 >= nb) { t0 -= nb; ++s0; }
     }
     if (zown) z[k + 1 + tid] = zz - zw * inv * zk;
-    for (int sx = 1 + tid + NT; sx <= nb; sx += NT) z[k + sx] -= wk[sx] * inv * zk;
+    if constexpr (!NARROW)
+      for (int sx = 1 + tid + NT; sx <= nb; sx += NT) z[k + sx] -= wk[sx] * inv * zk;
     if (retire) {
       if (town) {
         fac[(k - 1) * ld + tid] = (tid == 0) ? inv_prev : rold;
         if (tid == 0 && (STEADY || k + bw < p)) rnew -= wbw * inv * wbw;
         wp[tid] = rnew;
       }
-      for (int t = tid + NT; t <= bw; t += NT) {
-        fac[(k - 1) * ld + t] = wp[t];
-        wp[t] = entering(t);
-      }
+      if constexpr (!NARROW)
+        for (int t = tid + NT; t <= bw; t += NT) {
+          fac[(k - 1) * ld + t] = wp[t];
+          wp[t] = entering(t);
+        }
       if (ins && ++cpos == CH) { cpos = 0; ++cidx; }
     }
     inv_prev = inv;
@@ -254,9 +260,10 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     if (streaming && k >= 2 && k + 2 * bw < p && cpos != 0) {
       int kend = k + (CH - cpos);  // up to the end of the staged chunk
       if (kend > p - 2 * bw) kend = p - 2 * bw;
-      for (; k < kend; ++k) step(k, TrueTag{});
+      if (narrow) for (; k < kend; ++k) step(k, TrueTag{}, TrueTag{});
+      else for (; k < kend; ++k) step(k, TrueTag{}, FalseTag{});
     } else {
-      step(k, FalseTag{});
+      step(k, FalseTag{}, FalseTag{});
       ++k;
     }
   }
