@@ -306,3 +306,13 @@ def test_full_size_large_cones_certificate(hip, which):
     for k in ("loss", "grad", "target"):
         assert np.abs(pk[k].cpu().numpy() - inner[k][::-1]).max() <= 4e-6, k
     assert store.nbytes() < 0.01 * ct.numel() * 4
+    # Hybrid's heuristic branch (src/cave.py:201-204) and _average_ctrs (:222-228) at this size, vs the numpy oracle
+    from oracle import cave_oracle as O
+
+    heur = hip(c, y, MODE_HEURISTIC, -1.0, 0.2)
+    avg = O.average_ctrs(c)
+    assert np.abs(hip(c, None, MODE_AVG, 1.0, 0.0)["target"] - avg).max() <= 2e-6
+    t = O.heuristic_target(-y, c, 0.2)
+    assert np.abs(heur["target"] - t).max() <= 4e-6 and np.abs(heur["loss"] - O.cone_loss(y, t, -1.0)).max() <= 2e-6
+    pk = store.cone_op(ids, torch.tensor(y, device="cuda")[ids], MODE_HEURISTIC, -1.0, 0.2, outputs=("loss", "grad"))
+    assert np.abs(pk["loss"].cpu().numpy() - heur["loss"][::-1]).max() <= 2e-6
