@@ -517,7 +517,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   if constexpr (!BAND) for (int k = c.tid(); k < d; k += NT) w.wold[k] = 0.f;
   c.sync();
   double g0n = 0.0;
-  double reg_rel = 1e-10;  // Levenberg shift relative to max diag(H); raised when a step stalls
+  double reg_rel = 1e-12;  // Levenberg shift relative to max diag(H); raised when a step stalls
   bool converged = (p == 0);
   int it = 0;
   CAVE_T0();
@@ -822,7 +822,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       if (!(pgn > 1e-8 * g0n)) { converged = true; ++it; break; }
       if (reg_rel >= 1e-2) { converged = false; ++it; break; }
       reg_rel *= 1e3;
-    } else if (reg_rel > 1e-10) reg_rel *= 0.1;
+    } else if (reg_rel > 1e-12) reg_rel *= 0.1;
   }
   // final residual straight from theta (the iteration updated r incrementally), clipped for the epilogue
   if (p > 0) {
