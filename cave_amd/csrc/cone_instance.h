@@ -511,7 +511,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
                    (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d)) + align8u(4 * p);
   uint64_t vecs = 2 * align8u(4 * d);
   uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) + align8u(4 * p) +
-                   3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 32 * 8 * (uint64_t)(band / (p > 0 ? p : 1) + 2) + 8 * 2 * 32 * 4096;  // H, factor, ring window ((bw+1)^2 <= p*(bw+1)), staging
+                   3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096;  // H, factor, ring window ((bw+1)^2 <= p*(bw+1)), staging
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 256;
@@ -519,7 +519,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
 static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band) {
   const int64_t p = max_rows > 0 ? max_rows : 1;
   return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) +
-         align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 8 * 2 * 32 * 4096 + 256;
+         align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096 + 256;  // + staging buffers (at most 4096 entries each)
 }
 
 static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false) {

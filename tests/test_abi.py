@@ -39,6 +39,18 @@ def test_default_limits_and_arg_validation():
     assert lib.cave_hip_cone_dense(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == 0  # B == 0
     assert 0 < lib.cave_hip_packed_lds_bytes(190, 26, 700, 1) < lib.cave_hip_packed_lds_bytes(190, 26, 700, 0)
     assert lib.cave_hip_packed_lds_bytes(190, 5000, 700, 0) == -1
+    # large-cone entry points: sizing is monotone, bad workspaces / shapes are rejected before any launch
+    s1 = lib.cave_hip_large_slice_bytes(5155, 4950, 40000, 16000)
+    assert 0 < s1 < lib.cave_hip_large_slice_bytes(5155, 4950, 80000, 16000) < lib.cave_hip_large_slice_bytes(5155, 4950, 80000, 64000)
+    assert lib.cave_hip_large_slice_bytes(5155, 0, 40000, 16000) == -1
+    assert 0 < lib.cave_hip_packed_large_slice_bytes(1740, 900, 27900) < 1 << 20
+    none8 = [None] * 8
+    assert lib.cave_hip_cone_dense_large(None, None, 1, 4, 4, 0, 1.0, 0.0, 0, 64, 0, None, 1 << 20, 4, *none8) == -1  # null pointers
+    assert lib.cave_hip_cone_dense_large(None, None, 1, 70000, 4, 0, 1.0, 0.0, 0, 64, 0, None, 1 << 20, 4, *none8) == -1
+    assert b"bad shape" in lib.cave_hip_last_error()
+    assert lib.cave_hip_cone_dense_large(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 64, 0, None, 0, 0, *none8) == 0  # B == 0
+    assert lib.cave_hip_pack_large(None, 1, 4, 4, 64, None, 1 << 20, 4, None, None, None, 0, None, None) == -1
+    assert lib.cave_hip_cone_packed_large(None, None, None, 1, 0, 1.0, 0.0, 0, 0, None, 1 << 20, 4, *none8) == -1
 
 
 def test_status_codes_match_header():
