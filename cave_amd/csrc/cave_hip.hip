@@ -81,7 +81,7 @@ struct LargeWs {
   unsigned char* base;
   uint64_t slice;  // bytes per workgroup (< 4 GiB)
 };
-using CtxL = BlockCtx<4>;
+using CtxL = BlockCtx<4, true>;
 
 __global__ __launch_bounds__(CtxL::NT, 2) void cone_dense_large_kernel(DenseParams P, LargeWs W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

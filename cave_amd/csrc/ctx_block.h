@@ -14,11 +14,12 @@
 
 namespace cave {
 
-template <int NW>
+// WIDE: launched with a 256-VGPR budget even at 4 waves (the large-cone kernels): deeper scan prefetch
+template <int NW, bool WIDE = false>
 struct BlockCtx {
   static constexpr int NT = 64 * NW;
   static constexpr int TEAM = 4;
-  static constexpr int SCAN_UNROLL = (NW <= 2) ? 8 : 4;  // KiB per wave per batch (two batches in flight); VGPR budget
+  static constexpr int SCAN_UNROLL = (NW <= 2 || WIDE) ? 8 : 4;  // KiB per wave per batch (two batches in flight); VGPR budget
   static constexpr int PMAX = (NW <= 2) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2
   static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
   struct Scratch {
@@ -115,9 +116,11 @@ struct BlockCtx {
   }
 
   // publish this wave's count, return (sum over lower waves, total)
+  // (the exchange goes through LDS only, so the barrier waits for LDS only: global loads a caller has in
+  // flight -- the scan's prefetched batch -- stay in flight across it; __syncthreads() would drain them)
   __device__ __forceinline__ void wave_prefix(uint32_t wcount, uint32_t& pre, uint32_t& tot) {
     if (lane == 0) sc->u32[par][wave] = wcount;
-    __syncthreads();
+    sync_lds();
     pre = 0;
     tot = 0;
 #pragma unroll
@@ -193,7 +196,7 @@ struct BlockCtx {
       }
     };
     auto scan_batch = [&](const float4* buf, uint32_t r0) {
-      uint32_t rel[U], nzm = 0, wsum = 0;
+      uint32_t rel[U], nzm = 0, wsum = 0, nonempty = 0;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint32_t i = r0 + woff + (uint32_t)u * 64u;
@@ -203,6 +206,7 @@ struct BlockCtx {
         rel[u] = wsum + s.rel;
         nzm |= s.nzm << (4 * u);
         wsum += s.total;
+        nonempty |= (s.total != 0u ? 1u : 0u) << u;  // wave-uniform
       }
       uint32_t pre, tot;
       wave_prefix(wsum, pre, tot);
@@ -210,6 +214,7 @@ struct BlockCtx {
         const uint32_t base = cursor + pre;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          if (!((nonempty >> u) & 1u)) continue;  // this wave's chunk u holds no non-zero at all
           uint32_t i = r0 + woff + (uint32_t)u * 64u;
           if constexpr (COND) chunk_emit_cond(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, eflat, eval, cap);
           else chunk_emit(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, dump, eflat, eval, cap);
