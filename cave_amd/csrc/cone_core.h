@@ -555,7 +555,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // it is accumulated there with LDS atomics and copied out; otherwise straight into the workspace.
       const bool in_lds = w.band_hot && p <= ldh;
       double mu = (it < 6) ? 0.1 * ymax * pow(0.1, (double)it) : 0.0;
-      mu = fmax(mu, 0.03 * ymax * (pgn / g0n));
+      mu = fmax(mu, 0.03 * ymax * fmin(pgn / g0n, pow(0.7, (double)it)));  // capped: see the fast path below
       auto weight = [&](int k) -> double {
         const uint8_t u = v.usign[k];
         if (u == 0) return 1.0;
@@ -604,7 +604,10 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // flipping the active set every iteration (SP 5x5: 6.6 -> 3.9 iterations on average, worst 21 -> 7;
     // TSP-20: 5.87 -> 5.75, instances needing >= 8 iterations 52 -> 8 of 1024).
     {
-      const double mu = 0.1 * ymax * (pgn / g0n);
+      // (capped by 0.7^it: tied to the gradient alone the scale can hold itself up -- a stalled iteration keeps mu
+      // large, and a large mu keeps some cones from converging; the cap is far above pgn/g0n on every
+      // instance that converges normally)
+      const double mu = 0.1 * ymax * fmin(pgn / g0n, pow(0.7, (double)it));
       const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
       for (int k = c.tid(); k < d; k += NT) {
         const uint8_t u = v.usign[k];
