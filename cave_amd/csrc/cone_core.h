@@ -518,10 +518,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   c.sync();
   double g0n = 0.0;
   double reg_rel = 1e-12;  // Levenberg shift relative to max diag(H); raised when a step stalls
+  double cap07 = 1.0, sched01 = 1.0;  // 0.7^it and 0.1^it, kept as running products (pow() is ~300 instructions)
   bool converged = (p == 0);
   int it = 0;
   CAVE_T0();
-  for (; p > 0 && it < max_iter; ++it) {
+  for (; p > 0 && it < max_iter; ++it, cap07 *= 0.7, sched01 *= 0.1) {
     // gradient g = -M Pi(r) and projected-gradient norm
     gradient<C, PM1>(c, v, rc, w.g);
     double pgmax = 0.0;
@@ -554,8 +555,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // When the whole band fits the (idle) LDS ring window -- dense reduced systems, p <= bw + 1: TSP --
       // it is accumulated there with LDS atomics and copied out; otherwise straight into the workspace.
       const bool in_lds = w.band_hot && p <= ldh;
-      double mu = (it < 6) ? 0.1 * ymax * pow(0.1, (double)it) : 0.0;
-      mu = fmax(mu, 0.03 * ymax * fmin(pgn / g0n, pow(0.7, (double)it)));  // capped: see the fast path below
+      double mu = (it < 6) ? 0.1 * ymax * sched01 : 0.0;
+      mu = fmax(mu, 0.03 * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
       auto weight = [&](int k) -> double {
         const uint8_t u = v.usign[k];
         if (u == 0) return 1.0;
@@ -607,7 +608,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // (capped by 0.7^it: tied to the gradient alone the scale can hold itself up -- a stalled iteration keeps mu
       // large, and a large mu keeps some cones from converging; the cap is far above pgn/g0n on every
       // instance that converges normally)
-      const double mu = 0.1 * ymax * fmin(pgn / g0n, pow(0.7, (double)it));
+      const double mu = 0.1 * ymax * fmin(pgn / g0n, cap07);
       const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
       for (int k = c.tid(); k < d; k += NT) {
         const uint8_t u = v.usign[k];
