@@ -108,6 +108,7 @@ def main():
             dist.all_reduce(red)
         return o
 
+    cone_op_dense(ctrs, pred, mode, -1.0, 0.2, outputs=outs)  # one status-checked call: lets the wrapper settle its launch shape
     for _ in range(args.warmup):
         o = step()
     torch.cuda.synchronize()

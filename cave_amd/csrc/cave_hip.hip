@@ -38,19 +38,19 @@ __global__ CAVE_BOUNDS(C) void cone_dense_kernel(DenseParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C c;
   c.init(smem);
-  for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
+  // one workgroup per instance (grid = B): no loop, so nothing loop-invariant is hoisted into long live ranges
+  const int64_t b = blockIdx.x;
+  if (b >= P.B) return;
 #ifdef CAVE_STAMPS
-    for (int i = 0; i < 16; ++i) c.st[i] = 0;
-    unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < 16; ++i) c.st[i] = 0;
+  unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    run_dense_instance(c, smem, P, b);
+  run_dense_instance(c, smem, P, b);
 #ifdef CAVE_STAMPS
-    c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
-    c.st[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
-    if (c.tid() == 0 && b < 8192) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
+  c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
+  c.st[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
+  if (c.tid() == 0 && b < 8192) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
 #endif
-    __syncthreads();
-  }
 }
 
 template <class C>
@@ -58,10 +58,8 @@ __global__ CAVE_BOUNDS(C) void cone_pack_kernel(PackParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C c;
   c.init(smem);
-  for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
-    run_pack_instance(c, smem, P, b);
-    __syncthreads();
-  }
+  const int64_t b = blockIdx.x;
+  if (b < P.B) run_pack_instance(c, smem, P, b);
 }
 
 template <class C>
@@ -69,10 +67,8 @@ __global__ CAVE_BOUNDS(C) void cone_packed_kernel(PackedParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   C c;
   c.init(smem);
-  for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
-    run_packed_instance(c, smem, P, b);
-    __syncthreads();
-  }
+  const int64_t b = blockIdx.x;
+  if (b < P.B) run_packed_instance(c, smem, P, b);
 }
 
 // ---- large-cone path (cone_band.h): persistent 4-wave workgroups, arena = a slice of a global
@@ -146,7 +142,8 @@ static hipError_t ensure_lds(K kernel, uint32_t bytes) {
 #define CAVE_LAUNCH(KERNEL, WAVES, B, LDS, STREAM, PARAMS, WHAT)                                              \
   do {                                                                                                         \
     hipError_t e_;                                                                                             \
-    unsigned grid_ = (unsigned)((B) < (int64_t)1 << 30 ? (B) : (int64_t)1 << 30);                              \
+    if ((B) >= (int64_t)1 << 31) return fail(CAVE_E_INVALID, WHAT ": batch too large (B < 2^31)");                \
+    unsigned grid_ = (unsigned)(B);                                                                            \
     if ((WAVES) == 1) {                                                                                        \
       e_ = ensure_lds(KERNEL<Ctx1>, (uint32_t)(LDS));                                                          \
       if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                   \

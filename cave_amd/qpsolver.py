@@ -43,6 +43,23 @@ def _grow_limits(m: int, d: int) -> tuple[int, int]:
 # tier that worked next time instead of paying failed launches per call
 #   tier 1: one wave per instance, full 160 KiB LDS arena;  tier 2: large-cone path (global workspace)
 _tier: dict[tuple[int, int], int] = {}
+# shapes (m_max, d) whose cones were seen (by a status-checked launch) to fit / not to fit the 4-wave
+# workgroup shape (reduced systems up to 32 rows), the fastest one while the GPU has idle SIMDs
+_wide_ok: dict[tuple[int, int], bool] = {}
+
+
+def _auto_waves(B: int, m: int, d: int, check: bool) -> int:
+    """Waves per instance when the caller leaves it open.  Measured on TSP-20 (dense): 4 waves 191 us,
+    2 waves 215 us, 1 wave 236 us at B = 1024; one wave per instance wins beyond ~1300 instances (more
+    instances in flight).  Four waves hold reduced systems up to 32 rows and are only used once a
+    status-checked launch has shown the shape fits."""
+    if B > 1280:
+        return 1
+    ok = _wide_ok.get((m, d))
+    if ok is True or (ok is None and check):
+        return 4
+    return 2
+
 _large_hint: dict[tuple[int, int], tuple[int, int]] = {}  # (m, d) -> (nnz_cap, band_entries) that fitted
 
 
@@ -85,9 +102,8 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
 
     tight_ctrs (B, m_max, d) float32 zero-padded (src/dataset.py:143); pred_cost (B, d).
     ``outputs`` selects which of proj / rnorm / target / loss / grad are materialised.
-    ``waves``: wavefronts cooperating per instance (0 = library default 2; 1 or 2: reduced systems
-    up to 64 rows; 4: up to 32 rows — 5 % faster at TSP-20 / B = 1024 (203 vs 213 us) but its 128-VGPR
-    budget spills: 251 MB of HBM traffic per launch instead of 187 MB, so it is not the default).
+    ``waves``: wavefronts cooperating per instance (0 = chosen from the batch size and what is known
+    about the shape, see ``_auto_waves``; 1 or 2: reduced systems up to 64 rows; 4: up to 32 rows).
     With ``check=True`` (default) the per-instance status is read back (one host sync):
     a batch with a cone that does not fit is retried with one wave per instance and the largest
     LDS arena, then on the large-cone path (global workspace, band Newton systems: TSP-100,
@@ -168,7 +184,13 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             cap, lds = _grow_limits(m, d)
             launch(max(cap, nnz_cap), lds, 1)
         else:
-            launch(nnz_cap, lds_bytes, waves)
+            nw = waves if (waves != 0 or not auto) else _auto_waves(B, m, d, check)
+            launch(nnz_cap, lds_bytes, nw)
+            if check and auto and waves == 0 and nw == 4:
+                fits = not bool((status == ST_TOO_LARGE).any())
+                _wide_ok[(m, d)] = fits
+                if not fits:
+                    launch(nnz_cap, lds_bytes, 2)  # more than 32 reduced rows: two waves hold up to 64
         if check:
             if auto and tier == 0 and bool((status == ST_TOO_LARGE).any()):
                 tier = _tier[(m, d)] = 1
