@@ -177,27 +177,43 @@ CAVE_HD int32_t build_cone(C& c, Arena& ar, ConeBuild& cb) {
     cb.vnorm[i] = sqrtf(cb.rs2[r]);
   }
   c.sync();
-  for (int i = c.tid(); i < pr; i += NT) {
-    uint64_t a = hp[i], b = hn[i];
-    int same = 0, opp = 0;
-    uint32_t cand = 0xffffffffu;
-    for (int j = 0; j < pr; ++j) {
-      uint64_t hj = hp[j];
-      same += (hj == a);
-      if (hj == b) { opp++; if (cand == 0xffffffffu) cand = (uint32_t)j; }
+  // TEAM lanes share one row's scan over all signatures (lane `sub` takes j = sub, sub+TEAM, ...); the
+  // counts and, because a match only counts when it is unique, the SUM of matching indices are combined
+  // with the team reduction
+  {
+    constexpr int TEAM = C::TEAM;
+    constexpr int RPP = NT / TEAM;
+    const int sub = c.tid() % TEAM;
+    for (int base = 0; base < pr; base += RPP) {
+      const int i = base + c.tid() / TEAM;
+      const bool valid = i < pr;
+      const uint64_t a = valid ? hp[i] : 0ull, b = valid ? hn[i] : 0ull;
+      double same = 0.0, opp = 0.0, csum = 0.0;
+      if (valid)
+        for (int j = sub; j < pr; j += TEAM) {
+          const uint64_t hj = hp[j];
+          same += (hj == a) ? 1.0 : 0.0;
+          if (hj == b) { opp += 1.0; csum += (double)j; }
+        }
+      same = c.team_reduce_sum(same);
+      opp = c.team_reduce_sum(opp);
+      csum = c.team_reduce_sum(csum);
+      // exact verification (same columns, negated values), entries shared by the team as well
+      const bool try_it = valid && same == 1.0 && opp == 1.0;
+      const uint32_t cand = try_it ? (uint32_t)csum : 0u;
+      double bad = 0.0;
+      if (try_it) {
+        const uint32_t r = cb.vraw[i], q = cb.vraw[cand];
+        const uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
+        const uint32_t lo2 = cb.rptr[q], hi2 = cb.rptr[q + 1];
+        if ((hi - lo) != (hi2 - lo2)) bad = 1.0;
+        else
+          for (uint32_t e = (uint32_t)sub; e < hi - lo; e += (uint32_t)TEAM)
+            if (((cb.erc[lo + e] & 0xffffu) != (cb.erc[lo2 + e] & 0xffffu)) || (cb.eall[lo + e] != -cb.eall[lo2 + e])) bad = 1.0;
+      }
+      bad = c.team_reduce_sum(bad);
+      if (valid && sub == 0) twin[i] = (try_it && bad == 0.0) ? cand : 0xffffffffu;
     }
-    uint32_t t = 0xffffffffu;
-    if (same == 1 && opp == 1) {
-      // exact verification: same columns, negated values
-      uint32_t r = cb.vraw[i], q = cb.vraw[cand];
-      uint32_t lo = cb.rptr[r], hi = cb.rptr[r + 1];
-      uint32_t lo2 = cb.rptr[q], hi2 = cb.rptr[q + 1];
-      bool ok = (hi - lo) == (hi2 - lo2);
-      for (uint32_t e = 0; ok && e < hi - lo; ++e)
-        ok = ((cb.erc[lo + e] & 0xffffu) == (cb.erc[lo2 + e] & 0xffffu)) && (cb.eall[lo + e] == -cb.eall[lo2 + e]);
-      if (ok) t = cand;
-    }
-    twin[i] = t;
   }
   c.sync();
   for (int i = c.tid(); i < pr; i += NT) {
