@@ -54,6 +54,30 @@ def test_hip_random_cones_vs_oracle(hip):
         assert np.all(np.abs(o["rnorm"] - ro) <= 4e-6 * np.maximum(1.0, ro))
 
 
+def test_auto_launch_shape_falls_back(hip):
+    """No explicit `waves`: a checked call tries the 4-wave shape (reduced systems up to 32 rows), falls back to
+    two waves and then to one wave with the full LDS arena, and remembers what fitted per (m_max, d)."""
+    from cave_amd import qpsolver
+    from oracle import cave_oracle as O
+
+    rng = np.random.default_rng(9)
+    for m, fits in ((20, True), (40, False)):
+        A = (rng.standard_normal((8, m, 30)) * (rng.random((8, m, 30)) < 0.25)).astype(np.float32)  # fits the default nnz cap
+        A[:, :, 0] = 1.0                                                                              # no empty / unit rows
+        A[:, :, 1] = rng.standard_normal((8, m))
+        y = rng.standard_normal((8, 30)).astype(np.float32)
+        qpsolver._wide_ok.pop((m, 30), None)
+        qpsolver._tier.pop((m, 30), None)
+        o = hip(A, y, MODE_PROJECT, 1.0, 0.0)
+        assert (o["status"] == 0).all()
+        assert qpsolver._wide_ok[(m, 30)] is fits
+        assert qpsolver._tier.get((m, 30), 0) == (0 if fits else 1)  # 40 reduced rows also outgrow the default LDS arena
+        po, ro = O.batch_project(y, A)
+        assert np.abs(o["proj"] - po).max() <= 4e-6 * max(1.0, np.abs(y).max()) and np.abs(o["rnorm"] - ro).max() <= 4e-6
+        o2 = hip(A, y, MODE_PROJECT, 1.0, 0.0, check=False)  # unchecked calls use what was learnt
+        assert (o2["status"] == 0).all() and np.array_equal(o2["proj"], o["proj"])
+
+
 def test_hip_edge_cases(hip):
     y = np.array([[1, -2, 3, 0.5]], np.float32)
     o = hip(np.zeros((1, 3, 4), np.float32), y, MODE_EXACT, 1.0, 0.0)  # empty cone (src/cave.py:304-305)
