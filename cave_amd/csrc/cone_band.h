@@ -223,17 +223,27 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     for (int u = 0; u < U; ++u)
       if (uok[u]) win[poff[u]] = pr[u] - pa[u] * inv * pb[u];
     if constexpr (!NARROW)
-    while (s0 < na) {  // pairs beyond the first U per thread
-      if (t0 >= s0) {
-        const int sft = s0 + 1, tt = t0 + 1;
-        int slot = slot_k + sft;
+    while (s0 < na) {  // pairs beyond the first U per thread (wide bands), again U at a time: loads, then stores
+      double qa[U], qb[U], qr[U];
+      int qoff[U];
+      bool qok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        qok[u] = (s0 < na) && (t0 >= s0);
+        const int sc = qok[u] ? s0 : 0, tc = qok[u] ? t0 : 0;
+        int slot = slot_k + sc + 1;
         if (slot >= ld) slot -= ld;
-        auto row = win + slot * ld;
-        row[tt - sft] -= wk[sft] * inv * wk[tt];
+        qoff[u] = slot * ld + (tc - sc);
+        qa[u] = wk[sc + 1];
+        qb[u] = wk[tc + 1];
+        qr[u] = win[qoff[u]];
+        s0 += qn;
+        t0 += rn;
+        if (t0 >= nb) { t0 -= nb; ++s0; }
       }
-      s0 += qn;
-      t0 += rn;
-      if (t0 >= nb) { t0 -= nb; ++s0; }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (qok[u]) win[qoff[u]] = qr[u] - qa[u] * inv * qb[u];
     }
     if (zown) z[k + 1 + tid] = zz - zw * inv * zk;
     if constexpr (!NARROW)
@@ -256,6 +266,33 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     if constexpr (HOT) c.sync_lds();
     else c.sync();
   };
+  if (!streaming) {
+    // Dense system (p <= bw + 1: every row is resident in its own slot, nothing retires or enters): plain
+    // right-looking LDL^T.  A 32-lane strip per row, rows dealt round-robin to the strips -- unit-stride
+    // LDS accesses, no per-pair index arithmetic; the factor is copied out in one pass at the end.
+    constexpr int TX = NT >= 64 ? 32 : 1, TY = NT / TX;
+    const int tx = tid % TX, ty = tid / TX;
+    for (int k = 0; k < p; ++k) {
+      auto wk = win + k * ld;
+      const double dk = wk[0];
+      const double zk = z[k];
+      const double inv = (dk > 1e-300) ? 1.0 / dk : 0.0;
+      const int nb = p - 1 - k;
+      for (int sft = 1 + ty; sft <= nb; sft += TY) {
+        auto row = win + (k + sft) * ld;
+        const double ls = wk[sft] * inv;
+        for (int tt = sft + tx; tt <= nb; tt += TX) row[tt - sft] -= ls * wk[tt];
+      }
+      for (int sx = 1 + tid; sx <= nb; sx += NT) z[k + sx] -= wk[sx] * inv * zk;
+      if constexpr (HOT) c.sync_lds();
+      else c.sync();
+    }
+    for (int idx = tid; idx < p * ld; idx += NT) {
+      const int k = idx / ld, t = idx - k * ld;
+      const double v = win[idx];
+      fac[idx] = (t == 0) ? ((v > 1e-300) ? 1.0 / v : 0.0) : v;
+    }
+  } else {
   for (int k = 0; k < p;) {
     if (streaming && k >= 2 && k + 2 * bw < p && cpos != 0) {
       int kend = k + (CH - cpos);  // up to the end of the staged chunk
@@ -270,6 +307,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   {
     auto wp = win + ((p - 1) % ld) * ld;
     for (int t = tid; t <= bw; t += NT) fac[(p - 1) * ld + t] = (t == 0) ? inv_prev : wp[t];
+  }
   }
   c.sync();  // full barrier: the factor rows are in (workgroup-visible) global memory now
   CAVE_ACC(11);
