@@ -587,19 +587,47 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       auto accumulate = [&](auto Hacc, auto add) {
         for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
         c.sync();
-        for (int k = c.tid(); k < d; k += NT) {
-          const double wk = weight(k);
-          if (!(wk > 1e-14)) continue;
-          uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
-          for (uint32_t e1 = lo; e1 < hi; ++e1) {
-            uint32_t a, b;
-            double v1, v2;
-            csc_entry<PM1>(v, e1, a, v1);
-            const double va = wk * v1;
-            add(Hacc + a * ldh, va * v1);
-            for (uint32_t e2 = lo; e2 < e1; ++e2) {
-              csc_entry<PM1>(v, e2, b, v2);
-              add(Hacc + (b * ldh + (a - b)), va * v2);  // columns are sorted: b < a
+        // Four coordinates per thread at a time, their column extents and first two entries requested
+        // together: on the packed path the cone is read straight from the store (HBM / L2), and one
+        // dependent load per entry would cost a full memory latency each.
+        constexpr int G = 4;
+        for (int base = c.tid(); base < d; base += G * NT) {
+          uint32_t lo[G], hi[G], a0[G], a1[G];
+          double wk[G], x0[G], x1[G];
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            const int k = base + u * NT;
+            const bool in = k < d;
+            const int kc = in ? k : d - 1;
+            lo[u] = v.cptr[kc];
+            hi[u] = in ? v.cptr[kc + 1] : lo[u];
+            wk[u] = in ? weight(kc) : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;  // clamp: loads are unconditional
+            const uint32_t e0 = lo[u] < last ? lo[u] : last, e1 = lo[u] + 1u < last ? lo[u] + 1u : last;
+            csc_entry<PM1>(v, e0, a0[u], x0[u]);
+            csc_entry<PM1>(v, e1, a1[u], x1[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            if (!(wk[u] > 1e-14) || hi[u] == lo[u]) continue;
+            add(Hacc + a0[u] * ldh, wk[u] * x0[u] * x0[u]);
+            if (hi[u] - lo[u] >= 2u) {
+              add(Hacc + a1[u] * ldh, wk[u] * x1[u] * x1[u]);
+              add(Hacc + (a0[u] * ldh + (a1[u] - a0[u])), wk[u] * x1[u] * x0[u]);  // columns are sorted: a0 < a1
+            }
+            for (uint32_t e1 = lo[u] + 2u; e1 < hi[u]; ++e1) {  // columns with more than two entries (cut rows)
+              uint32_t a, b;
+              double v1, v2;
+              csc_entry<PM1>(v, e1, a, v1);
+              const double va = wk[u] * v1;
+              add(Hacc + a * ldh, va * v1);
+              for (uint32_t e2 = lo[u]; e2 < e1; ++e2) {
+                csc_entry<PM1>(v, e2, b, v2);
+                add(Hacc + (b * ldh + (a - b)), va * v2);
+              }
             }
           }
         }
