@@ -334,12 +334,16 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
       int k = khi;
       // two rows' factor entries in flight
       auto row_entry = [&](int kk) -> double { return (kk >= klo && lane < bw) ? stg[b * csz + (kk - klo) * ld + 1 + lane] : 0.0; };
-      double fnext = row_entry(k);
+      // everything that does not depend on x -- the factor row, its reciprocal pivot, z_k -- is requested one
+      // row ahead, so the loop-carried chain is just the wave reduction and the shift
+      auto pivot_entry = [&](int kk) -> double { return kk >= klo ? stg[b * csz + (kk - klo) * ld] : 0.0; };
+      auto z_entry = [&](int kk) -> double { return kk >= klo ? z[kk] : 0.0; };
+      double fnext = row_entry(k), f0next = pivot_entry(k), znext = z_entry(k);
       for (; k >= klo; --k) {
-        const double fcur = fnext;
+        const double fcur = fnext, f0 = f0next, zk = znext;
         fnext = row_entry(k - 1);
-        const double f0 = stg[b * csz + (k - klo) * ld];
-        const double zk = z[k];
+        f0next = pivot_entry(k - 1);
+        znext = z_entry(k - 1);
         const double part = c.wave_sum(fcur * xw);  // entries past the matrix end multiply x = 0
         const double xk = f0 * (zk - part);
         if (lane == 0) x[k] = xk;

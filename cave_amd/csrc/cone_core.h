@@ -556,7 +556,10 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // Nearly-zero residual (y inside or on the cone): the caller's `rnorm < 1e-7` inside test
     // (src/cave.py:218) needs rnorm itself resolved, so the gradient test is tightened.
     const double tol_it = (f < 1e-8 * yy) ? 1e-4 * tol : tol;
-    if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy) { converged = true; break; }
+    // Absolute floor: rnorm = sqrt(2 f) <= 4.5e-8 settles that test for good (this iterate is in the cone, so
+    // the true distance is smaller still) and bounds the error of proj by 9e-8 -- points inside a cone with
+    // degenerate multipliers otherwise creep towards f = 0 at a linear rate.
+    if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy || f <= 1e-15) { converged = true; break; }
     if constexpr (BAND) {
       // SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
       // the CHKS smoothing of the one-sided clip at scale mu (1/2 at the kink, -> the 0/1 activity D_kk
@@ -867,8 +870,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // Either we are done (projected gradient at round-off level), or the Newton direction
       // was dominated by a (near-)null direction of a rank-deficient Hessian: damp harder,
       // which turns the step towards steepest descent, and go on.
-      if (!(pgn > 1e-8 * g0n)) { converged = true; ++it; break; }
-      if (reg_rel >= 1e-2) { converged = false; ++it; break; }
+      // (The looser gradient test is only trusted once the step has been damped to 1e-6: with the 1e-12
+      // shift a Hessian of condition 1e12+ gives a direction made of round-off, and "no gain along it"
+      // says nothing about optimality.)
+      if (reg_rel >= 1e-6 && !(pgn > 1e-8 * g0n)) { converged = true; ++it; break; }
+      if (reg_rel >= 1e-2) { converged = !(pgn > 1e-8 * g0n); ++it; break; }
       reg_rel *= 1e3;
     } else if (reg_rel > 1e-12) reg_rel *= 0.1;
   }

@@ -18,7 +18,11 @@ t0 = time.time(); n = 0; bad = 0; nondet = 0; worst = 0.0; nfail = 0; nsaved = 0
 from collections import Counter
 nd_kind = Counter(); st_kind = Counter(); inst_kind = Counter()
 OUTS = ("proj", "rnorm", "target", "loss", "grad")
+last_report = time.time()
 while time.time() - t0 < T:
+    if time.time() - last_report > 60:  # the GPU box kills a run that is silent for 7 minutes
+        last_report = time.time()
+        print(f"... {int(time.time() - t0)} s, {n} batches/instances so far, {bad} mismatches", flush=True)
     kind = int(rng.integers(0, 5))
     if kind == 0:
         nn = int(rng.integers(4, 21)); B = 48

@@ -19,7 +19,11 @@ rng = np.random.default_rng(seed)
 t0 = time.time(); n = 0; bad = 0; worst = 0.0; spread = 0.0; itmax = 0
 st = Counter()
 OUTS = ("proj", "rnorm", "target", "loss", "grad")
+last_report = time.time()
 while time.time() - t0 < T:
+    if time.time() - last_report > 60:  # the GPU box kills a run that is silent for 7 minutes
+        last_report = time.time()
+        print(f"... {int(time.time() - t0)} s, {n} batches/instances so far, {bad} mismatches", flush=True)
     kind = int(rng.integers(0, 5))
     if kind == 0:
         A, y, _ = synth.tsp_batch(int(rng.integers(8, 36)), 12, seed=int(rng.integers(1 << 30)))
@@ -71,4 +75,4 @@ while time.time() - t0 < T:
         bad += 1
         print("PACK FAILED kind", kind, A.shape, repr(ex)[:200])
 print(f"instances {n} mismatches {bad} worst err {worst:.2e} launch-to-launch spread {spread:.2e} max iters {itmax}")
-print("status by (kind, code):", dict(sorted(st.items())))
+print("status by (kind, code):", dict(sorted(st.items(), key=str)))
