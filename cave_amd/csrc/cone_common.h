@@ -138,6 +138,7 @@ struct SolveWork {
   double* rc;      // [d]  Pi(res)
   double* theta;   // [p]
   double* ttry;    // [p]
+  double* told;    // [p]  theta two iterations ago (zig-zag extrapolation)
   double* g;       // [p]
   double* dv;      // [p]  model gradient in the inner loop, then the search direction
   double* g2;      // [p]  right-hand side / H*step scratch

@@ -541,6 +541,39 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   for (; p > 0 && it < max_iter; ++it, cap07 *= 0.7, sched01 *= 0.1) {
     // gradient g = -M Pi(r) and projected-gradient norm
     gradient<C, PM1>(c, v, rc, w.g);
+    // Zig-zag extrapolation.  On degenerate cones (duplicated generators, y inside the cone) the iteration can
+    // settle into a two-cycle of active sets and crawl along a valley at a linear rate.  From iteration 10 on,
+    // every second iteration first minimises f exactly along theta - theta(two iterations ago), the valley
+    // direction; instances that converge normally never get here.
+    if ((it & 1) == 0) {
+      if (it >= 10) {
+        double psi0 = 0.0, amax = 1e300;
+        for (int i = c.tid(); i < p; i += NT) {
+          const double di = theta[i] - w.told[i];
+          w.dv[i] = di;
+          psi0 += w.g[i] * di;
+          if (!v.vkind[i] && di < 0.0) amax = fmin(amax, theta[i] / (-di));
+        }
+        psi0 = c.reduce_sum(psi0);
+        amax = -c.reduce_max(-amax);
+        c.sync();
+        if (psi0 < 0.0 && amax > 0.0) {
+          gather_mt<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
+          const double alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
+          for (int i = c.tid(); i < p; i += NT) {
+            double t = theta[i] + alpha * w.dv[i];
+            if (!v.vkind[i] && t < 0.0) t = 0.0;
+            theta[i] = t;
+          }
+          c.sync();
+          gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+          f = refresh_clipped(c, v, r, rc);
+          gradient<C, PM1>(c, v, rc, w.g);
+        }
+      }
+      for (int i = c.tid(); i < p; i += NT) w.told[i] = theta[i];
+      c.sync();
+    }
     double pgmax = 0.0;
     for (int i = c.tid(); i < p; i += NT) {
       double gi = w.g[i];

@@ -176,6 +176,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.bstg = hot_get<double>(hot, ar, 2u * (uint32_t)w.bch * ld);
       w.g2 = hot_get<double>(hot, ar, pp);
       w.ttry = hot_get<double>(hot, ar, pp);
+      w.told = hot_get<double>(hot, ar, pp);
       w.dv = hot_get<double>(hot, ar, pp);
       w.theta = hot_get<double>(hot, ar, pp);
       w.g = hot_get<double>(hot, ar, pp);
@@ -195,6 +196,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.wold = ar.get<float>(d);
       w.theta = ar.get<double>(pp);
       w.ttry = ar.get<double>(pp);
+      w.told = ar.get<double>(pp);
       w.g = ar.get<double>(pp);
       w.dv = ar.get<double>(pp);
       w.g2 = ar.get<double>(pp);
@@ -463,7 +465,7 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
                    + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // signatures | fill
   uint64_t vecs = 2 * align8u(4 * d);                                                            // y, avg
   uint64_t solve = 3 * align8u(8 * d) + align8u(4 * d)                                           // res, tvec/q, rc, wold
-                   + 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, H, act, long rows
+                   + 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, told, H, act, long rows
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
@@ -510,7 +512,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
                    align8u(rows_raw) + align8u(2 * m) +
                    (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d)) + align8u(4 * p);
   uint64_t vecs = 2 * align8u(4 * d);
-  uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) + align8u(4 * p) +
+  uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 8 * align8u(8 * p) + 2 * align8u(p) + align8u(4 * p) +
                    3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096;  // H, factor, ring window ((bw+1)^2 <= p*(bw+1)), staging
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
@@ -518,7 +520,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
 }
 static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band) {
   const int64_t p = max_rows > 0 ? max_rows : 1;
-  return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 7 * align8u(8 * p) + 2 * align8u(p) +
+  return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 8 * align8u(8 * p) + 2 * align8u(p) +
          align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096 + 256;  // + staging buffers (at most 4096 entries each)
 }
 
@@ -529,7 +531,7 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(4 * (p + 1)) + align8u(p);                                               // mptr, vkind
   s += 2 * (align8u(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : align8u(4 * (int64_t)max_nnz)));  // CSR + CSC (+ values)
   s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
-  s += 6 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
+  s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
   if (s > kMaxLds) return -1;
   return (int32_t)s;
 }
