@@ -95,7 +95,7 @@ class ConeStore:
                     pack_large(x, cap, n_rows, n_nnz, None, 0, status)
                     if not bool((status == _lib.ST_TOO_LARGE).any()):
                         break
-                    cap = min(2 * cap, max(m * d, 64))
+                    cap = min(4 * cap, max(m * d, 64))
                 lim = ("large", cap)
                 break
             _raise_for_status(status, "ConeStore pack")

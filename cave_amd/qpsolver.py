@@ -89,7 +89,7 @@ def _raise_for_status(status: torch.Tensor, what: str) -> None:
     if code == ST_TOO_LARGE:
         raise HipSolverError(
             f"{what}: {bad} cone(s) (first index {first}) did not fit the workspace of the large-cone path "
-            "after 4 size doublings (non-zeros / band of the reduced system).")
+            "after four 4x size increases (non-zeros / band of the reduced system).")
     if code == ST_BAD_INPUT:
         raise ValueError(f"{what}: non-finite input in {bad} instance(s), first index {first}.")
     raise HipSolverError(f"{what}: unknown status {code}")
@@ -169,7 +169,7 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
                 launch_large(cap, band)
                 if not check or not bool((status == ST_TOO_LARGE).any()):
                     break
-                cap, band = min(2 * cap, max(m * d, 64)), 4 * band
+                cap, band = min(4 * cap, max(m * d, 64)), 4 * band  # dense cones: m*d non-zeros, p*p band entries
             _large_hint[(m, d)] = (cap, band)
 
         auto = lds_bytes == 0

@@ -284,6 +284,23 @@ def test_large_path_dense_generators_vs_oracle(hip):
     assert np.abs(o["proj"] - po).max() <= 4e-6 * max(1.0, np.abs(y).max()) and np.abs(o["rnorm"] - ro).max() <= 4e-6
 
 
+def test_large_path_dense_cone_workspace_growth(hip):
+    """A fully dense cone (200 generators in 150 dimensions: 30 000 non-zeros, a 200 x 200 Newton system) needs
+    several workspace-size increases from the structured-cone guess; each projection is KKT-certified."""
+    from certificate import assert_projection
+    from cave_amd import qpsolver
+
+    rng = np.random.default_rng(17)
+    A = rng.standard_normal((2, 200, 150)).astype(np.float32)
+    y = rng.standard_normal((2, 150)).astype(np.float32)
+    qpsolver._large_hint.pop((200, 150), None)
+    o = hip(A, y, MODE_PROJECT, 1.0, 0.0)
+    assert (o["status"] == 0).all()
+    assert qpsolver._large_hint[(200, 150)][0] >= 30000
+    for b in range(2):
+        assert_projection(A[b], y[b], o["proj"][b], what=("dense200", b))
+
+
 def test_large_path_reference_fixture(hip, golden):
     """12x12 / 30x30 grid shortest-path cones and one TSP-100 cone against the reference's own outputs
     (tests/golden/large.npz; SciPy needed 44 s for the 30x30 instance and 26 min for the TSP-100 one)."""
