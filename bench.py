@@ -230,6 +230,26 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
         train_step()
     torch.cuda.synchronize()
     out["train_step_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+    # same step, per-instance status examined one call later instead of right after the launch (no host sync per step)
+    from cave_amd.cave import flush_checks
+
+    cave_lazy = innerConeAlignedCosine(_Model(), solver="hip", seed=0, solver_kwargs={"check": "lazy"})
+
+    def train_step_lazy():
+        loss = cave_lazy(reg(x), batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(5):
+        train_step_lazy()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        train_step_lazy()
+    flush_checks()
+    torch.cuda.synchronize()
+    out["train_step_lazy_check_ms"] = 1e3 * (time.perf_counter() - t0) / 50
     # the same step captured in a HIP graph (the C-ABI launch path does no allocation, attribute
     # change or host sync of its own when status checking is deferred)
     try:

@@ -226,6 +226,37 @@ def test_modules_autograd_reduction_and_branching(golden):
     assert np.abs(t.cpu().numpy() - g["generic_min_exact_target"]).max() <= 4e-6
 
 
+def test_lazy_status_check_raises_one_call_later():
+    """solver_kwargs={'check': 'lazy'}: no host sync per step, the verdict of a launch arrives with the next call."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.cave import EPO, flush_checks, innerConeAlignedCosine
+    from cave_amd.dataset import ConeStore, PackedBatch
+
+    class _M:
+        modelSense = EPO.MINIMIZE
+
+    ctrs, costs, _ = synth.tsp_batch(12, 16, seed=1)
+    store = ConeStore.from_dense(torch.tensor(ctrs, device="cuda"))
+    batch = PackedBatch(store, torch.arange(16, device="cuda"))
+    strict = innerConeAlignedCosine(_M(), solver="hip", seed=0)
+    lazy = innerConeAlignedCosine(_M(), solver="hip", seed=0, solver_kwargs={"check": "lazy"})
+    good = torch.tensor(costs, device="cuda", requires_grad=True)
+    a, b = strict(good, batch), lazy(good, batch)
+    assert torch.equal(a, b)
+    b.backward()
+    flush_checks()                                    # nothing wrong so far
+    bad = torch.tensor(costs, device="cuda")
+    bad[3, 5] = float("nan")
+    lazy(bad, batch)                                  # launches; its status is only queued
+    with pytest.raises(ValueError):
+        lazy(good, batch)                             # ... and examined here
+    flush_checks()
+    with pytest.raises(ValueError):
+        strict(bad, batch)                            # the strict mode raises at once
+
+
 def test_training_example_reduces_regret():
     """BASELINE configs[0] shape (SP 5x5, 100 instances, batch 32) end to end with solver='hip':
     the loop of code_sample.py:48-60 on Gurobi-free exact cones; dense and packed cone formats."""
