@@ -28,10 +28,12 @@ __device__ unsigned long long g_stamp_buf[16 * 8192];
 using Ctx1 = WaveCtx;      // one wave per instance, reduced systems up to 64 rows
 using Ctx4 = BlockCtx<4>;  // 4-wave workgroup per instance, reduced systems up to 32 rows
 using Ctx2 = BlockCtx<2>;  // 2-wave workgroup per instance
+using CtxW = BlockCtx<4, true>;  // 4 waves with the full register budget: for launches whose LDS arena allows one
+                                 // workgroup per CU anyway (TSP-50: 100-160 KB); reduced systems up to 64 rows
 
 // launch bounds: NT threads; for the 4-wave context ask for 4 waves per SIMD (= 4 workgroups per CU,
 // the residency LDS allows), which caps the kernel at 128 VGPRs
-#define CAVE_BOUNDS(C) __launch_bounds__(C::NT, (C::NT == 64 ? 1 : (C::NT == 128 ? 2 : 4)))
+#define CAVE_BOUNDS(C) __launch_bounds__(C::NT, C::MIN_WAVES_PER_EU)
 
 template <class C>
 __global__ CAVE_BOUNDS(C) void cone_dense_kernel(DenseParams P) {
@@ -148,6 +150,10 @@ static hipError_t ensure_lds(K kernel, uint32_t bytes) {
       e_ = ensure_lds(KERNEL<Ctx1>, (uint32_t)(LDS));                                                          \
       if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                   \
       hipLaunchKernelGGL(KERNEL<Ctx1>, dim3(grid_), dim3(Ctx1::NT), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS); \
+    } else if ((WAVES) == 8) {                                                                                 \
+      e_ = ensure_lds(KERNEL<CtxW>, (uint32_t)(LDS));                                                          \
+      if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                   \
+      hipLaunchKernelGGL(KERNEL<CtxW>, dim3(grid_), dim3(CtxW::NT), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS); \
     } else if ((WAVES) == 2) {                                                                                 \
       e_ = ensure_lds(KERNEL<Ctx2>, (uint32_t)(LDS));                                                          \
       if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                   \
@@ -163,7 +169,7 @@ static hipError_t ensure_lds(K kernel, uint32_t bytes) {
 
 static bool waves_ok(int32_t& waves) {
   if (waves == 0) waves = 2;  // measured best at the benchmark size, no register spills, 64-row systems
-  return waves == 1 || waves == 2 || waves == 4;
+  return waves == 1 || waves == 2 || waves == 4 || waves == 8;  // 8 = four waves, wide register budget
 }
 
 }  // namespace cave

@@ -20,7 +20,8 @@ struct BlockCtx {
   static constexpr int NT = 64 * NW;
   static constexpr int TEAM = 4;
   static constexpr int SCAN_UNROLL = (NW <= 2 || WIDE) ? 8 : 4;  // KiB per wave per batch (two batches in flight); VGPR budget
-  static constexpr int PMAX = (NW <= 2) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2
+  static constexpr int PMAX = (NW <= 2 || WIDE) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2 (or WIDE)
+  static constexpr int MIN_WAVES_PER_EU = WIDE ? 1 : (NW <= 2 ? NW : 4);
   static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
   struct Scratch {
     double f64[2][8];

@@ -87,7 +87,7 @@ class ConeStore:
                         tier += 1
                         if tier == 1:
                             cap, lds = _grow_limits(m, d)
-                            lim = (cap, lds, 1)
+                            lim = (cap, lds, 8)
                         continue
                     break
                 cap = _large_guess(m, d)[0]
@@ -175,8 +175,10 @@ class ConeStore:
         """Waves per instance.  Two cooperating waves shorten the critical path while the GPU has idle
         SIMDs (about one instance per SIMD: B <= ~1024 on 256 CUs); beyond that one wave per instance
         puts more instances in flight and wins on throughput (measured crossover between 1024 and 2048)."""
-        if self.waves in (1, 2, 4):
+        if self.waves in (1, 2, 4, 8):
             return self.waves if (self.waves != 4 or self.fits4) else 2
+        if self.lds_bytes > 80 * 1024:
+            return 8  # one workgroup per CU whatever the shape: four waves with the wide register budget (64 rows)
         if self.fits4 and B <= 1280:
             return 4  # measured (TSP-20, packed): 116 vs 129 us at B = 256, 138 vs 145 us at B = 1024
         return 2 if B <= 1280 else 1

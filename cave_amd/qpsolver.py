@@ -41,7 +41,8 @@ def _grow_limits(m: int, d: int) -> tuple[int, int]:
 
 # shapes (m_max, d) whose cones did not fit the default (structured-cone) arena: go straight to the
 # tier that worked next time instead of paying failed launches per call
-#   tier 1: one wave per instance, full 160 KiB LDS arena;  tier 2: large-cone path (global workspace)
+#   tier 1: full 160 KiB LDS arena (one workgroup per CU, four waves with the wide register budget: waves=8);
+#   tier 2: large-cone path (global workspace)
 _tier: dict[tuple[int, int], int] = {}
 # shapes (m_max, d) whose cones were seen (by a status-checked launch) to fit / not to fit the 4-wave
 # workgroup shape (reduced systems up to 32 rows), the fastest one while the GPU has idle SIMDs
@@ -182,7 +183,7 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             run_large()
         elif tier == 1:
             cap, lds = _grow_limits(m, d)
-            launch(max(cap, nnz_cap), lds, 1)
+            launch(max(cap, nnz_cap), lds, 8)  # full arena = one workgroup per CU: four waves with the wide register budget
         else:
             nw = waves if (waves != 0 or not auto) else _auto_waves(B, m, d, check)
             launch(nnz_cap, lds_bytes, nw)
@@ -195,7 +196,7 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             if auto and tier == 0 and bool((status == ST_TOO_LARGE).any()):
                 tier = _tier[(m, d)] = 1
                 cap, lds = _grow_limits(m, d)
-                launch(max(cap, nnz_cap), lds, 1)
+                launch(max(cap, nnz_cap), lds, 8)  # full arena = one workgroup per CU: four waves with the wide register budget
             if auto and tier == 1 and bool((status == ST_TOO_LARGE).any()):
                 tier = _tier[(m, d)] = 2
                 run_large()

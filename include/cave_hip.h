@@ -69,7 +69,8 @@ int32_t cave_hip_device_count(void);
  * either to let the library choose (cave_hip_default_limits reports the
  * choice so a caller can grow it after CAVE_ST_TOO_LARGE).
  * waves: wavefronts cooperating on one instance (workgroup = `waves` x 64 threads).
- *   0 = library default (2);  1 or 2: reduced systems up to 64 rows;  4: up to 32 rows (an instance with
+ *   0 = library default (2);  1 or 2: reduced systems up to 64 rows;  4: up to 32 rows;  8: four waves with
+ *   the full register budget (up to 64 rows; for launches whose LDS arena leaves one workgroup per CU) (an instance with
  *   more reports CAVE_ST_TOO_LARGE: the host layer tries 4 first, then 2, and remembers per shape).
  * More waves shorten the per-instance critical path (useful while B is about the number of SIMDs,
  * 1024 on MI355X: TSP-20, B = 1024 takes 187 / 212 / 236 us with 4 / 2 / 1 waves); one wave per

@@ -27,10 +27,11 @@ def hip():
     return impl
 
 
-@pytest.mark.parametrize("waves", [4, 1])
+@pytest.mark.parametrize("waves", [4, 1, 8])
 @pytest.mark.parametrize("file,tag", CASES)
 def test_hip_matches_reference_outputs(hip, golden, file, tag, waves):
-    """Both workgroup shapes: 4 cooperating waves per instance (default) and one wave per instance."""
+    """Workgroup shapes: 4 cooperating waves per instance, one wave per instance, and 4 waves with the wide
+    register budget (waves=8, the shape of full-arena launches)."""
     check_case(lambda *a: hip(*a, waves=waves), golden, file, tag)
 
 

@@ -40,7 +40,7 @@ while time.time() - t0 < T:
     po, ro = O.batch_project(-y, A)
     mode = int(rng.integers(0, 3))
     ref = None
-    for waves in (1, 2, 4):
+    for waves in (1, 2, 4, 8):
         o = cone_op_dense(At, yt, mode, -1.0, 0.2, waves=waves, outputs=OUTS, check=False, lds_bytes=160 * 1024,
                           nnz_cap=max(64, A.shape[1] * A.shape[2]) if kind >= 2 else 4 * (A.shape[1] + A.shape[2]) + 256)
         o2 = cone_op_dense(At, yt, mode, -1.0, 0.2, waves=waves, outputs=OUTS, check=False, lds_bytes=160 * 1024,
