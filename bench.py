@@ -6,9 +6,15 @@
 One "step" = one pass of the fused hot path (dense scan -> projection -> CaVE+ target ->
 cosine loss -> d loss/d pred) over one batch of synthetic TSP-20 cones, B = 1024 per GPU
 (BASELINE.json configs[1]), inputs resident in HBM, through the C ABI (cave_hip_cone_dense).
-N > 1: one process per GPU (torchrun), the batch shards by instance (weak scaling, no
-data-path collective); the scalar loss is all-reduced over RCCL each step.
-Rank 0 prints ONE JSON line.
+Successive steps rotate over `--rotate` different batches (default 4 x 183 MB > the 256 MB
+Infinity Cache), so the cones of a step are read from HBM, not from a cache warmed by the step before.
+
+N > 1: one process per GPU.  Either the driver starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: RANK is set), or
+`python bench.py --gpus N` starts them itself: the parent, which never touches the GPU, launches
+`torch.distributed.run` as a child process, relays rank 0's JSON line and exits with the child's code.
+The batch shards by instance (weak scaling, no data-path collective); the scalar loss is
+all-reduced over RCCL each step.  Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
@@ -16,6 +22,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,9 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -33,27 +42,119 @@ def parse():
     ap.add_argument("--tsp", type=int, default=20, help="TSP size n (d = n(n-1)/2)")
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step")
     ap.add_argument("--instances", type=int, default=1000, help="distinct instances in the dataset")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct batches the timed steps cycle through")
     ap.add_argument("--mode", default="inner", choices=["project", "exact", "inner"])
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances timed on the host for cpu_baseline (0=skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip packed-path / train-step side measurements")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the side measurements at the instance sizes of BASELINE configs 3-5")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / JSON-relay check without a GPU (gloo, no kernels; CPU tests)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(ctrs_np, costs_np, n_sample):
-    """The CPU oracle (oracle/nnls_oracle.c, Lawson-Hanson, 1 thread) in the reference's loop shape."""
+# --------------------------------------------------------------------------- self-launch
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Parent of a `python bench.py --gpus N` call (N > 1, RANK unset).  Nothing here touches HIP
+    (no torch.cuda call, no dlopen of the extension): the ranks are children of a child process."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    out, err = proc.communicate()
+    line = None
+    for ln in out.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(err[-4000:])
+        sys.stderr.write(f"\nbench.py: the {args.gpus}-rank run failed (exit code {proc.returncode}, "
+                         f"JSON line {'found' if line else 'missing'})\n")
+        return proc.returncode or 1
+    print(line)
+    return 0
+
+
+def dry_run(args) -> int:
+    """What a rank does without a GPU: rendezvous, barrier, max-over-ranks timing, rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    red = torch.zeros(2)
+    for _ in range(args.steps):
+        red[0], red[1] = float(rank), float(args.batch)
+        if world > 1:
+            dist.all_reduce(red)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "cone projections/sec", "value": None, "unit": "projections/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "instances_seen": float(red[1])}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# --------------------------------------------------------------------------- CPU baseline
+
+def _oracle_chunk(job):
+    from oracle import cave_oracle as O
+
+    y, A = job
+    O.batch_project(y, A)
+    return len(y)
+
+
+def cpu_baseline(ctrs_np, signed_np, n_sample, label):
+    """The CPU restatement of the reference's nnls path (oracle/nnls_oracle.c, Lawson-Hanson, fp64) in the
+    reference's loop shape: serial (`processes=1`, src/cave.py:257) and over all host cores (the
+    `processes=0` pool mode, src/cave.py:259; here a thread pool -- the C call releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import cave_oracle as O
 
     O.build()
     n = min(n_sample, len(ctrs_np))
-    O.batch_project(-costs_np[:2], ctrs_np[:2])  # warm
+    O.batch_project(signed_np[:1], ctrs_np[:1])  # warm
     t0 = time.perf_counter()
-    O.batch_project(-costs_np[:n], ctrs_np[:n])
+    O.batch_project(signed_np[:n], ctrs_np[:n])
     dt = time.perf_counter() - t0
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {"value": n / dt, "unit": "projections/s", "cores": 1, "kind": "port",
-           "sample": f"{n} TSP instances of the benchmark batch, serial loop, {dt:.1f} s"}
-    try:  # informational: the reference's third-party solver in the reference's loop shape (src/cave.py:257,303-309)
+           "sample": f"{n} {label} instances of the benchmark batch, serial loop, {dt:.1f} s"}
+    if nproc > 1:
+        per = max(1, min(8, n // nproc))
+        n_all = min(len(ctrs_np), max(n, per * nproc * 4))
+        jobs = [(signed_np[i:i + per], ctrs_np[i:i + per]) for i in range(0, n_all, per)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nproc) as ex:
+            done = sum(ex.map(_oracle_chunk, jobs))
+        dta = time.perf_counter() - t0
+        out["all_cores"] = {"value": done / dta, "cores": nproc,
+                            "sample": f"{done} instances over {nproc} host threads, {dta:.1f} s"}
+    # the reference's own third-party solvers, where the box has them
+    try:
         import numpy as np
         from scipy.optimize import nnls
 
@@ -61,15 +162,44 @@ def cpu_baseline(ctrs_np, costs_np, n_sample):
         t0 = time.perf_counter()
         for i in range(k):
             A = ctrs_np[i][np.abs(ctrs_np[i]).sum(axis=1) > 1e-7]
-            nnls(np.asfortranarray(A.T), -costs_np[i])
+            nnls(np.asfortranarray(A.T), signed_np[i])
         out["scipy_nnls_projections_per_s_1core"] = k / (time.perf_counter() - t0)
-    except Exception:  # noqa: BLE001
-        pass
+    except Exception as e:  # noqa: BLE001
+        out["scipy_nnls"] = f"unavailable ({type(e).__name__})"
+    out["clarabel"] = clarabel_baseline(ctrs_np, signed_np, min(16, n))
     return out
 
 
-def main():
-    args = parse()
+def clarabel_baseline(ctrs_np, signed_np, k):
+    """`_project_clarabel` with max_iter=3 (src/cave.py:267-295), the comparator the north star names.
+    cvxpy + clarabel are not in this image; when they are missing the line says so and every ratio in
+    this file is against the nnls path."""
+    try:
+        import clarabel  # noqa: F401
+        import cvxpy as cp
+    except Exception as e:  # noqa: BLE001
+        return {"status": "unavailable", "reason": f"{type(e).__name__}: {e}"[:120],
+                "note": "north-star ratio '>=100x over solver=clarabel' is reported against the nnls CPU path instead"}
+    import numpy as np
+
+    t0 = time.perf_counter()
+    for i in range(k):
+        A = ctrs_np[i][np.abs(ctrs_np[i]).sum(axis=1) > 1e-7]
+        lam = cp.Variable(A.shape[0], nonneg=True)
+        prob = cp.Problem(cp.Minimize(cp.sum_squares(A.T @ lam - signed_np[i])))
+        prob.solve(solver=cp.CLARABEL, max_iter=3)
+    return {"status": "timed", "projections_per_s_1core": k / (time.perf_counter() - t0), "max_iter": 3}
+
+
+# --------------------------------------------------------------------------- main measurement
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_run:
+        sys.exit(dry_run(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -80,28 +210,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
 
-    # ---- synthetic dataset: `instances` TSP-n cones, this rank's batch of ids
+    # ---- synthetic dataset: `instances` TSP-n cones; this rank's R rotating batches of ids
     ctrs_np, costs_np, _ = synth.tsp_batch(args.tsp, args.instances, seed=0)
-    ids = (np.arange(args.batch) + rank * args.batch) % args.instances
+    R = max(1, args.rotate)
     rng = np.random.default_rng(1234 + rank)
-    pred_np = costs_np[ids] + rng.normal(0, 0.05, size=costs_np[ids].shape).astype(np.float32)
-    ctrs = torch.tensor(ctrs_np[ids], device=dev)  # dense wire format, resident in HBM
-    pred = torch.tensor(pred_np, device=dev)
+    batches = []
+    for r in range(R):
+        ids = (np.arange(args.batch) + rank * args.batch + r * (args.instances // R + 7)) % args.instances
+        pred_np = costs_np[ids] + rng.normal(0, 0.05, size=costs_np[ids].shape).astype(np.float32)
+        batches.append((ids, pred_np, torch.tensor(ctrs_np[ids], device=dev), torch.tensor(pred_np, device=dev)))
+    ids, pred_np, ctrs, pred = batches[0]
     B, m_max, d = ctrs.shape
     mode = {"project": _lib.MODE_PROJECT, "exact": _lib.MODE_EXACT, "inner": _lib.MODE_INNER}[args.mode]
     outs = ("proj", "rnorm") if mode == _lib.MODE_PROJECT else ("loss", "grad")
     red = torch.zeros(2, device=dev)
 
-    def step():
-        o = cone_op_dense(ctrs, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+    def step(i):
+        _, _, c, p = batches[i % R]
+        o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
         if world > 1 and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
             red[0] = o["loss"].sum()
             red[1] = float(B)
@@ -109,48 +244,51 @@ def main():
         return o
 
     cone_op_dense(ctrs, pred, mode, -1.0, 0.2, outputs=outs)  # one status-checked call: lets the wrapper settle its launch shape
-    for _ in range(args.warmup):
-        o = step()
+    for i in range(args.warmup):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        o = step()
-    ev1.record()
+    status_all = []
+    for i in range(args.steps):
+        o = step(i)
+        if i >= args.steps - R:
+            status_all.append(o["status"])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert bool((o["status"] == 0).all()), "solver reported failures"
+    assert all(bool((s == 0).all()) for s in status_all), "solver reported failures"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
-    # ---- dominant kernel duration (HIP events on the launch stream, kernel launches only)
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-    for a, b in kev:
+    # ---- dominant kernel duration: HIP events on the launch stream around single launches, rotating batches
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5 * R)]
+    for i, (a, b) in enumerate(kev):
+        _, _, c, p = batches[i % R]
         a.record()
-        cone_op_dense(ctrs, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+        cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
         b.record()
     torch.cuda.synchronize()
-    kern_ms = float(np.median([a.elapsed_time(b) for a, b in kev]))
-    m_i = (np.abs(ctrs_np[ids]).sum(axis=2) > 0).sum(axis=1)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
     # algorithmic bytes per launch, dense operator format: cone once, y once, outputs once
-    out_bytes = (4 * d + 4) if mode == _lib.MODE_PROJECT else (4 * d + 4)
-    alg_bytes = int((4 * m_i * d).sum() + B * (4 * d + out_bytes))
+    alg = []
+    for bids, _, _, _ in batches:
+        m_i = (np.abs(ctrs_np[bids]).sum(axis=2) > 0).sum(axis=1)
+        alg.append(int((4 * m_i * d).sum() + B * (4 * d + 4 * d + 4)))
+    alg_bytes = int(np.mean(alg))
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
-    traffic = None  # HBM bytes per launch from the PMC passes (tools/diag/pmc_run.sh -> profiles/)
+    traffic, traffic_src = None, None  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/diag/pmc_run.sh)
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        pm = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
         if pm.get("workload") == f"tsp{args.tsp}_b{args.batch}_{args.mode}":
-            traffic = pm.get("hbm_bytes_per_launch")
+            traffic, traffic_src = pm.get("hbm_bytes_per_launch"), PMC_SUMMARY
     except Exception:  # noqa: BLE001
         pass
     if rank == 0:
@@ -160,23 +298,61 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"TSP-{args.tsp} DFJ tight cones, {args.instances} instances, batch {B}/GPU, "
-                                   f"CaVE+ ({args.mode}) solver='hip', dense (B,m_max,d) wire format",
+                                   f"CaVE+ ({args.mode}) solver='hip', dense (B,m_max,d) wire format, "
+                                   f"{R} rotating batches ({R * ctrs.numel() * 4 / 1e6:.0f} MB of cones per GPU)",
                        "batch_per_gpu": B, "d": d, "m_max": m_max, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "cone_dense_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes},
-            "newton_iters_mean": float(o["iters"].float().mean()),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "cone_dense_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                         "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
+                         R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
+            "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
         }
         if not args.no_extras:
             res.update(extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs))
             if not args.no_other_configs and world == 1:
                 res["other_configs"] = other_configs(dev)
         if args.cpu_sample > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(ctrs_np[ids], pred_np, args.cpu_sample)
+            res["cpu_baseline"] = cpu_baseline(ctrs_np[ids], -pred_np, args.cpu_sample, f"TSP-{args.tsp}")
+            res["gpu_over_cpu_1core_nnls"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
+    if world > 1 and not args.no_extras:
+        sharded_store_leg(args, ctrs_np, costs_np, dev, mode, outs, rank, world)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_store_leg(args, ctrs_np, costs_np, dev, mode, outs, rank, world):
+    """N > 1 side measurement (stderr, not the JSON line): the dataset's ragged cones are dealt to ranks
+    balanced by their non-zeros (ConeStore.from_ragged_shard) and every rank projects its whole shard."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cave_amd.dataset import ConeStore
+
+    ragged = [torch.from_numpy(c[np.abs(c).sum(axis=1) > 0]) for c in ctrs_np]
+    store = ConeStore.from_ragged_shard(ragged, rank, world)
+    ids = torch.arange(store.n, device=dev)
+    pred = torch.tensor(costs_np[store.global_ids.numpy()], device=dev)
+    for _ in range(5):
+        store.cone_op(ids, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        store.cone_op(ids, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0, float(store.n), float(store.nbytes())], device=dev, dtype=torch.float64)
+    tm = t.clone()
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        sys.stderr.write(json.dumps({"sharded_packed_store": {
+            "ranks": world, "instances": int(t[1]), "projections_per_s": float(t[1]) * 50 / float(tm[0]),
+            "max_shard_bytes": int(tm[2]), "balance": "sum of non-zeros (LPT)"}}) + "\n")
 
 
 def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
@@ -200,8 +376,19 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
     torch.cuda.synchronize()
     dtp = time.perf_counter() - t0
     assert bool((o["status"] == 0).all())
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in kev:
+        a.record()
+        store.cone_op(tid, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+        b.record()
+    torch.cuda.synchronize()
+    pk_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    pk_bytes = store.algorithmic_bytes(tid)
     out["packed_store"] = {"projections_per_s": len(ids) * K / dtp, "ms_per_step": 1e3 * dtp / K,
-                           "store_bytes": store.nbytes(), "algorithmic_bytes": store.algorithmic_bytes(tid)}
+                           "store_bytes": store.nbytes(), "algorithmic_bytes": pk_bytes, "kernel_ms": pk_ms,
+                           "roofline": {"bound": "hbm", "achieved": pk_bytes / (pk_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": pk_bytes / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "kernel": "cone_packed_kernel"}}
 
     # training step in the shape of code_sample.py:23-59: linear predictor, CaVE+ loss, Adam(lr 1e-2)
     class _Model:
@@ -289,46 +476,77 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
 
 
 def other_configs(dev):
-    """Side measurements (not `value`): one GPU's share of BASELINE configs 3-5 on the packed store.
-    A few unique synthetic cones per size (the dense form of TSP-100 is 102 MB per instance) are
-    replicated to the per-GPU batch with independent predictions."""
+    """Side measurements (not `value`): one GPU's share of BASELINE configs 3-5 on the packed store, every
+    batch slot a DISTINCT synthetic cone (generated in coordinate form, densified on the GPU a chunk at a
+    time and packed), each with its own roofline and a sub-sampled CPU figure."""
+    import numpy as np
     import torch
 
     from cave_amd import _lib, synth
     from cave_amd.dataset import ConeStore
 
-    def run(name, gen, n_unique, B, mode, chunk):
-        ctrs, costs, _ = gen(n_unique)
-        c = torch.tensor(ctrs, device=dev)
-        store = ConeStore.from_dense(c, chunk=chunk)
-        del c
-        ids = torch.arange(B, device=dev) % n_unique
+    def run(name, kind, size, B, mode, chunk, cpu_n, cpu_note):
+        items, costs, _ = synth.coo_batch(kind, size, B, seed=0)
+        d = int(costs.shape[1])
+        m_max = max(it[3] for it in items)
+        store = ConeStore.from_chunks_lazy(lambda i: synth.densify_on(items[i:i + chunk], d, dev, m_max),
+                                           list(range(0, B, chunk)))
+        ids = torch.arange(B, device=dev)
         g = torch.Generator(device="cpu").manual_seed(1)
-        pred = torch.tensor(costs, device=dev)[ids] + 0.05 * torch.randn(B, costs.shape[1], generator=g).to(dev)
+        pred_np = costs + 0.05 * torch.randn(B, d, generator=g).numpy()
+        pred = torch.tensor(pred_np, device=dev)
         outs = ("loss", "grad")
         o = store.cone_op(ids, pred, mode, -1.0, 0.2, outputs=outs)
         torch.cuda.synchronize()
         K = 5
+        kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         t0 = time.perf_counter()
-        for _ in range(K):
+        for a, b in kev:
+            a.record()
             store.cone_op(ids, pred, mode, -1.0, 0.2, check=False, outputs=outs)
+            b.record()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
-        return {"workload": name, "batch_per_gpu": B, "unique_cones": n_unique, "d": int(costs.shape[1]),
-                "reduced_rows_max": store.max_rows, "path": "large (band LDL^T, global workspace)" if store.large else "fast (LDS)",
-                "projections_per_s": B / dt, "ms_per_step": 1e3 * dt, "newton_iters_mean": float(o["iters"].float().mean()),
-                "newton_iters_max": int(o["iters"].max())}
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+        alg = store.algorithmic_bytes(ids)
+        res = {"workload": name, "batch_per_gpu": B, "distinct_cones": B, "d": d,
+               "reduced_rows_max": store.max_rows,
+               "path": "large (band LDL^T, global workspace)" if store.large else "fast (LDS)",
+               "projections_per_s": B / dt, "ms_per_step": 1e3 * dt, "newton_iters_mean": float(o["iters"].float().mean()),
+               "newton_iters_max": int(o["iters"].max()),
+               "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "cone_packed_large_kernel" if store.large else "cone_packed_kernel",
+                            "kernel_ms": k_ms, "algorithmic_bytes": alg, "format": "packed store"}}
+        if cpu_n > 0:
+            from oracle import cave_oracle as O
+
+            dense = synth.densify_on(items[:cpu_n], d, torch.device("cpu"), m_max).numpy()
+            t0 = time.perf_counter()
+            O.batch_project(-pred_np[:cpu_n], dense)
+            dtc = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": cpu_n / dtc, "unit": "projections/s", "cores": 1, "kind": "port",
+                                   "sample": f"{cpu_n} instance(s) of this batch, serial, {dtc:.1f} s"}
+        else:
+            res["cpu_baseline"] = {"value": None, "unit": "projections/s", "cores": 1, "kind": "port", "sample": cpu_note}
+        return res
 
     out = []
-    try:
-        out.append(run("configs[2] TSP-50, CaVE Exact, 4096/8 GPUs", lambda n: synth.tsp_batch(50, n, seed=0), 32, 512,
-                       _lib.MODE_EXACT, 32))
-        out.append(run("configs[3] TSP-100, QP branch of CaVE Hybrid (inner_ratio 0.2), 2048/4 GPUs",
-                       lambda n: synth.tsp_batch(100, n, seed=0), 8, 512, _lib.MODE_INNER, 4))
-        out.append(run("configs[4] shortest path 30x30, CaVE+ (inner), 8192/8 GPUs",
-                       lambda n: synth.sp_batch(30, 30, n, seed=0), 32, 1024, _lib.MODE_INNER, 32))
-    except Exception as e:  # noqa: BLE001 - side measurement only
-        out.append({"error": repr(e)[:300]})
+    specs = [
+        ("configs[2] TSP-50, CaVE Exact, 4096/8 GPUs", "tsp", 50, 512, _lib.MODE_EXACT, 32, 2, ""),
+        ("configs[3] TSP-100, QP branch of CaVE Hybrid (inner_ratio 0.2), 2048/4 GPUs", "tsp", 100, 512,
+         _lib.MODE_INNER, 4, 0,
+         "not timed in the default run: one TSP-100 instance takes ~26 min in scipy.optimize.nnls "
+         "(measured when tests/golden/large.npz was generated)"),
+        ("configs[4] shortest path 30x30, CaVE+ (inner), 8192/8 GPUs", "sp", (30, 30), 1024, _lib.MODE_INNER, 32, 0,
+         "not timed in the default run: one 30x30 instance takes ~44 s in scipy.optimize.nnls "
+         "(measured when tests/golden/large.npz was generated)"),
+    ]
+    for spec in specs:
+        try:
+            out.append(run(*spec))
+        except Exception as e:  # noqa: BLE001 - side measurement only
+            out.append({"workload": spec[0], "error": repr(e)[:300]})
     return out
 
 

@@ -52,11 +52,50 @@ class ConeStore:
         return cls.from_chunks(chunks)
 
     @classmethod
+    def from_ragged_shard(cls, ctrs: list[torch.Tensor], rank: int, world: int, chunk: int = 1024) -> "ConeStore":
+        """This rank's shard of `optDatasetConstrs.ctrs` under data parallelism: instances
+        are dealt to ranks balanced by their non-zero counts (what the packed store and the kernels' work
+        scale with), not by instance count; each GPU packs and keeps only its own cones.  The same
+        partition is computed on every rank.  `store.global_ids[j]` is the dataset index of store slot j;
+        `store.local_ids(ids)` maps dataset indices owned by this rank to store slots."""
+        from .dist import weighted_shards
+
+        weights = [int(torch.count_nonzero(c)) for c in ctrs]
+        mine = weighted_shards(weights, world)[rank]
+        self = cls.from_ragged([ctrs[int(i)] for i in mine], chunk)
+        self.global_ids = torch.as_tensor(mine, dtype=torch.int64)
+        self.shard = (int(rank), int(world))
+        return self
+
+    def local_ids(self, dataset_ids: torch.Tensor) -> torch.Tensor:
+        """Store slots of dataset indices (all of which must belong to this rank's shard)."""
+        gids = getattr(self, "global_ids", None)
+        ids = torch.as_tensor(dataset_ids, dtype=torch.int64).cpu()
+        if gids is None:
+            return ids
+        pos = torch.searchsorted(gids, ids)
+        if bool((pos >= gids.numel()).any()) or not torch.equal(gids[pos.clamp(max=gids.numel() - 1)], ids):
+            raise IndexError("dataset index not in this rank's shard")
+        return pos
+
+    @classmethod
     def from_chunks(cls, chunks: list[torch.Tensor]) -> "ConeStore":
+        return cls.from_chunks_lazy(lambda ch: ch, chunks)
+
+    @classmethod
+    def from_chunks_lazy(cls, make_chunk, keys: list) -> "ConeStore":
+        """Like from_chunks, but chunk k is produced on demand by `make_chunk(keys[k])` (called twice per
+        chunk: count pass and fill pass) -- for datasets whose dense form does not fit anywhere at once
+        (TSP-100: 102 MB per instance)."""
         lib = _lib.load()
         dev = torch.device("cuda", torch.cuda.current_device())
-        d = int(chunks[0].shape[2])
-        self = cls(d, dev)
+
+        class _Chunks:
+            def __iter__(self):
+                return (make_chunk(k) for k in keys)
+
+        chunks = _Chunks()
+        d = None  # known once the first chunk has been produced
         stream = _lib.current_stream()
         # pass 1: counts.  Default launch limits are sized for small structured cones; a chunk that does
         # not fit is re-counted with one wave per instance and the full 160 KiB arena, then on the
@@ -73,7 +112,10 @@ class ConeStore:
         counts, limits = [], []
         for ch in chunks:
             x = ch.to(device=dev, dtype=torch.float32).contiguous()
+            del ch
             B, m, _ = x.shape
+            if d is None:
+                d = int(x.shape[2])
             n_rows = torch.empty(B, dtype=torch.int32, device=dev)
             n_nnz = torch.empty(B, dtype=torch.int32, device=dev)
             status = torch.empty(B, dtype=torch.int32, device=dev)
@@ -101,6 +143,9 @@ class ConeStore:
             _raise_for_status(status, "ConeStore pack")
             counts.append((n_rows, n_nnz))
             limits.append(lim)
+        if d is None:
+            raise ValueError("ConeStore: no chunks")
+        self = cls(d, dev)
         n_rows = torch.cat([c[0] for c in counts]).to(torch.int64)
         n_nnz = torch.cat([c[1] for c in counts]).to(torch.int64)
         N = int(n_rows.numel())

@@ -13,6 +13,23 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _predictor(d):
+    torch.manual_seed(7)
+    return torch.nn.Linear(4, d).double()
+
+
+def _features(n):
+    g = torch.Generator().manual_seed(8)
+    return torch.randn(n, 4, generator=g, dtype=torch.float64)
+
+
+def _surrogate(pred, loss_np, grad_np):
+    """Per-instance loss tensor with the oracle's value and the oracle's d loss_b / d pred_b."""
+    g = torch.tensor(grad_np, dtype=pred.dtype)
+    lin = (pred * g).sum(dim=1)
+    return lin - lin.detach() + torch.tensor(loss_np, dtype=pred.dtype)
+
+
 def _worker(rank, world, port, q):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -32,7 +49,24 @@ def _worker(rank, world, port, q):
         g = global_mean_loss(x)
         g.backward()
         losses.append((float(g), x.grad.numpy().copy()))
-    q.put((rank, lo, hi, seed, losses))
+    # predictor gradient: replicated nn.Linear under real DDP (gradient AVERAGE) + global_mean_loss must give
+    # the gradient of the unsharded reduction='mean' loss
+    pgrads = {}
+    for mode in ("mean", "sum"):
+        lin = _predictor(costs.shape[1])
+        net = torch.nn.parallel.DistributedDataParallel(lin) if mode == "mean" else lin
+        feats = _features(len(ctrs))[lo:hi]
+        pred = net(feats)
+        exact = O.ConeLossOracle(minimize=True, inner=False, reduction="none")
+        l, gpred = exact(pred.detach().numpy(), ctrs[lo:hi])
+        li = _surrogate(pred, l, gpred)
+        global_mean_loss(li, grad_reduce=mode).backward()
+        if mode == "sum":
+            from cave_amd.dist import allreduce_grads_sum
+
+            allreduce_grads_sum(lin.parameters())
+        pgrads[mode] = [p.grad.numpy().copy() for p in lin.parameters()]
+    q.put((rank, lo, hi, seed, losses, pgrads))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +94,36 @@ def test_sharded_loss_matches_unsharded():
         got0, grad0 = res[0][4][step]
         got1, grad1 = res[1][4][step]
         assert abs(got0 - want) < 1e-6 and abs(got1 - want) < 1e-6  # both ranks hold the global mean
-        assert np.allclose(grad0, 1.0 / 21) and np.allclose(grad1, 1.0 / 21)
+        # default convention: local gradient world/B_global, to be AVERAGED over ranks by DDP
+        assert np.allclose(grad0, 2.0 / 21) and np.allclose(grad1, 2.0 / 21)
+    # single-process gradient of the unsharded mean loss w.r.t. the predictor
+    lin = _predictor(costs.shape[1])
+    pred = lin(_features(len(ctrs)))
+    l, gpred = O.ConeLossOracle(minimize=True, inner=False, reduction="none")(pred.detach().numpy(), ctrs)
+    _surrogate(pred, l, gpred).mean().backward()
+    want = [p.grad.numpy() for p in lin.parameters()]
+    for r in res:
+        for mode in ("mean", "sum"):
+            for got, w in zip(r[5][mode], want):
+                assert np.allclose(got, w, rtol=1e-9, atol=1e-12), (r[0], mode)
+
+
+def test_weighted_shards_balance_by_nnz():
+    from cave_amd.dist import weighted_shards
+
+    rng = np.random.default_rng(0)
+    w = rng.integers(100, 5000, size=1000)
+    for world in (1, 2, 4, 8):
+        parts = weighted_shards(w, world)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(1000))
+        loads = [w[p].sum() for p in parts]
+        assert max(loads) - min(loads) <= w.max()  # LPT: within one instance of even
+    # equal weights -> equal counts
+    assert [len(p) for p in weighted_shards(np.ones(1024), 8)] == [128] * 8
+    # a by-count split of a skewed dataset would be far off; by-weight is not
+    w2 = np.r_[np.full(100, 5000), np.full(900, 100)]
+    loads = [w2[p].sum() for p in weighted_shards(w2, 4)]
+    assert max(loads) / min(loads) < 1.05
 
 
 def test_shard_range_balanced():
