@@ -8,9 +8,11 @@ sign flip, projection under no_grad, target construction, cosine loss
 HIP kernel launch (cave_amd/csrc/cave_hip.hip) behind a
 ``torch.autograd.Function``; ``reduction`` stays in torch.
 
-The reference's CPU solvers ('clarabel', 'nnls') and its torch.compile path
-('apgd') are not re-implemented: this package has no CPU fallback, and a
-constructor asked for them says so.
+Constructor signatures are the reference's (src/cave.py:93-100,152-163), including the
+default ``solver='clarabel'``; ``'hip'`` is the one name added to the accepted set (src/cave.py:111).
+The reference's own backends ('clarabel', 'nnls', 'apgd') are not shipped in this package and
+there is no CPU fallback: asking for one raises ImportError, the way the reference refuses
+``solver='clarabel'`` without cvxpy (src/cave.py:113-117).
 """
 
 from __future__ import annotations
@@ -31,8 +33,7 @@ _REFERENCE_SOLVERS = ("apgd", "clarabel", "nnls")
 def _dense_shape_settled(tight_ctrs) -> bool:
     from . import qpsolver
 
-    key = (int(tight_ctrs.shape[1]), int(tight_ctrs.shape[2]))
-    return key in qpsolver._tier or key in qpsolver._wide_ok
+    return (int(tight_ctrs.shape[1]), int(tight_ctrs.shape[2])) in qpsolver._settled
 
 
 def _packed_kwargs(kwargs: dict) -> dict:
@@ -49,26 +50,34 @@ _pending_checks: list = []
 
 
 def flush_checks() -> None:
-    """Examine the status of every lazily checked launch so far; raises like the strict check would have."""
-    from .qpsolver import _raise_for_status
+    """Examine the status of every lazily checked launch so far; raises like the strict check would have.
+
+    A launch whose cached shape (waves / LDS tier per (m_max, d)) turned out too small for a later batch
+    forgets that shape first, so the next call for it runs status-checked and re-tiers (two waves, full
+    arena, large-cone path) instead of failing again.  The failed instances of the lazy launch itself
+    contributed zero loss and zero gradient (masked on the device), so no NaN reached the optimizer."""
+    from . import _lib as L
+    from .qpsolver import _raise_for_status, forget_shape
 
     while _pending_checks:
-        host, event, what = _pending_checks.pop(0)
+        host, event, what, shape = _pending_checks.pop(0)
         event.synchronize()
         _pinned_free.setdefault(host.numel(), []).append(host)  # pinned allocations are slow: keep them
+        if shape is not None and bool((host == L.ST_TOO_LARGE).any()):
+            forget_shape(*shape)
         _raise_for_status(host, what)
 
 
 _pinned_free: dict = {}
 
 
-def _defer_check(status: torch.Tensor, what: str) -> None:
+def _defer_check(status: torch.Tensor, what: str, shape=None) -> None:
     free = _pinned_free.get(status.numel())
     host = free.pop() if free else torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
     host.copy_(status, non_blocking=True)
     event = torch.cuda.Event()
     event.record()
-    _pending_checks.append((host, event, what))
+    _pending_checks.append((host, event, what, shape))
 
 
 class _ConeLossFunction(torch.autograd.Function):
@@ -88,11 +97,18 @@ class _ConeLossFunction(torch.autograd.Function):
                 kwargs = dict(kwargs, check=True)  # first call for this shape: strict, so the launch tier can settle
                 lazy = False
             o = cone_op_dense(tight_ctrs, pred_cost, mode, sign, inner_ratio, outputs=("loss", "grad"), **kwargs)
+        loss, grad = o["loss"], o["grad"]
         if lazy:
-            _defer_check(o["status"], "solver='hip' (lazy check)")
-        ctx.save_for_backward(o["grad"])
+            shape = None if isinstance(tight_ctrs, PackedBatch) else (int(tight_ctrs.shape[1]), int(tight_ctrs.shape[2]))
+            _defer_check(o["status"], "solver='hip' (lazy check)", shape)
+            # the verdict arrives one call late: until then a failed instance (NaN-filled outputs) must not
+            # reach the optimizer -- mask it on the device (no host sync)
+            ok = o["status"] == 0
+            loss = torch.where(ok, loss, torch.zeros_like(loss))
+            grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
+        ctx.save_for_backward(grad)
         ctx.pred_meta = (pred_cost.device, pred_cost.dtype)
-        return o["loss"].to(device=pred_cost.device, dtype=pred_cost.dtype)
+        return loss.to(device=pred_cost.device, dtype=pred_cost.dtype)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -135,14 +151,14 @@ class abstractConeAlignedCosine(optModule):
 class exactConeAlignedCosine(abstractConeAlignedCosine):
     """CaVE Exact: full projection onto the cone of binding-constraint normals (src/cave.py:84-129)."""
 
-    def __init__(self, optmodel, solver: str = "hip", solver_kwargs: dict | None = None, processes: int = 1,
+    def __init__(self, optmodel, solver: str = "clarabel", solver_kwargs: dict | None = None, processes: int = 1,
                  reduction: str = "mean") -> None:
         super().__init__(optmodel, processes, reduction)
         if solver not in ("hip",) + _REFERENCE_SOLVERS:
-            raise ValueError(f"Invalid solver: {solver}. Must be 'hip', 'apgd', 'clarabel', or 'nnls'.")
+            raise ValueError(f"Invalid solver: {solver}. Must be 'apgd', 'clarabel', 'nnls' or 'hip'.")  # src/cave.py:111-112
         if solver != "hip":
-            raise ValueError(f"solver='{solver}' is the reference's own backend and is not part of cave_amd; "
-                             "this package provides solver='hip' only (no CPU fallback).")
+            raise ImportError(f"solver='{solver}' is the reference's own backend and is not shipped with cave_amd "
+                              "(no cvxpy/clarabel/SciPy path, no CPU fallback): pass solver='hip'.")  # cf. :113-117
         _lib.load()  # ImportError if the HIP extension or a device is missing (cf. src/cave.py:113-117)
         self.solver = solver
         self.solver_kwargs = dict(solver_kwargs or {})
@@ -161,7 +177,7 @@ class innerConeAlignedCosine(exactConeAlignedCosine):
 
     _INNER_DEFAULTS: dict[str, dict] = {"hip": {}}
 
-    def __init__(self, optmodel, solver: str = "hip", solver_kwargs: dict | None = None, max_iter: int = 3,
+    def __init__(self, optmodel, solver: str = "clarabel", solver_kwargs: dict | None = None, max_iter: int = 3,
                  solve_ratio: float = 1.0, inner_ratio: float = 0.2, processes: int = 1, reduction: str = "mean",
                  seed: int | None = None) -> None:
         if solver_kwargs is None:

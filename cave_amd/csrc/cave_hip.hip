@@ -1,11 +1,13 @@
 // cave_hip.hip — gfx950 kernels and the C ABI declared in include/cave_hip.h.
 //
-// One 64-lane wavefront per training instance (workgroup = one wave, grid = B):
-//   1. stream the instance's dense (m_max x d) block from HBM with 16-byte loads,
-//      8 KiB in flight per wave, keeping only the non-zeros (ordered CSR in LDS);
+// One workgroup of 1, 2 or 4 cooperating 64-lane wavefronts per training instance (grid = B; the
+// `waves` argument of the C ABI picks the shape, see include/cave_hip.h):
+//   1. stream the instance's dense (m_max x d) block from HBM with 16-byte loads, two batches in
+//      flight per wave, keeping only the non-zeros (ordered CSR in LDS);
 //   2. classify rows / pair equalities / build CSC            (cone_core.h build_cone)
-//   3. projected semismooth Newton in fp64, Hessian solve in registers (solve_cone)
+//   3. projected semismooth Newton in fp64, Newton systems solved in registers (solve_cone)
 //   4. fused epilogue: proj, rnorm, loss target, loss, d loss / d pred.
+// Cones beyond LDS run on persistent 4-wave workgroups over a global workspace (the *_large kernels).
 // Instances are independent, so the block->instance map is the identity and no
 // XCD-aware remap is needed (nothing is shared through L2).
 #include <hip/hip_runtime.h>
@@ -214,7 +216,7 @@ int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int
   if (!ctrs && m_max > 0) return fail(CAVE_E_INVALID, "cone_dense: ctrs is null");
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense: pred is null");
   if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "cone_dense: bad nnz_cap / lds_bytes");
-  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_dense: waves must be 0, 1 or 4");
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_dense: waves must be 0, 1, 2, 4 or 8");
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
   P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
@@ -231,7 +233,7 @@ int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t
   if (B == 0) return CAVE_OK;
   if (!ctrs || !n_rows || !n_nnz) return fail(CAVE_E_INVALID, "pack_count: null pointer");
   if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "pack_count: bad limits");
-  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_count: waves must be 0, 1 or 4");
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_count: waves must be 0, 1, 2, 4 or 8");
   PackParams P;
   memset(&P, 0, sizeof(P));
   P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
@@ -249,7 +251,7 @@ int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t 
   if (!ctrs || !store) return fail(CAVE_E_INVALID, "pack_fill: null pointer");
   if (store->d != d || slot0 < 0 || slot0 + B > store->n) return fail(CAVE_E_INVALID, "pack_fill: store mismatch");
   if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "pack_fill: bad limits");
-  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_fill: waves must be 0, 1 or 4");
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_fill: waves must be 0, 1, 2, 4 or 8");
   PackParams P;
   memset(&P, 0, sizeof(P));
   P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
@@ -274,7 +276,7 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
   if (B == 0) return CAVE_OK;
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed: pred is null");
   if (lds_bytes <= 0 || (uint32_t)lds_bytes > kMaxLds) return fail(CAVE_E_INVALID, "cone_packed: bad lds_bytes");
-  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_packed: waves must be 0, 1 or 4");
+  if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_packed: waves must be 0, 1, 2, 4 or 8");
   PackedParams P;
   P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
   P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;

@@ -14,8 +14,8 @@
 //   minimises the C^1 piecewise-quadratic
 //        f(theta) = 1/2 || Pi(y - M^T theta) ||^2 ,  theta_i >= 0 for unpaired rows
 //   which is solved by a projected semismooth Newton method in fp64
-//   (generalised Hessian M D M^T, Bertsekas epsilon-active set, Armijo
-//   backtracking on the projection arc).  proj = y - res*, rnorm = ||res*||_2.
+//   (smoothed generalised Hessian M W M^T, active-set inner loop on the
+//   quadratic model, exact line search on the true f).  proj = y - res*, rnorm = ||res*||_2.
 #pragma once
 #include "cone_common.h"
 #include "cone_band.h"
@@ -589,10 +589,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // Nearly-zero residual (y inside or on the cone): the caller's `rnorm < 1e-7` inside test
     // (src/cave.py:218) needs rnorm itself resolved, so the gradient test is tightened.
     const double tol_it = (f < 1e-8 * yy) ? 1e-4 * tol : tol;
-    // Absolute floor: rnorm = sqrt(2 f) <= 4.5e-8 settles that test for good (this iterate is in the cone, so
+    // Residual floor: rnorm = sqrt(2 f) <= 4.5e-8 settles that test for good (this iterate is in the cone, so
     // the true distance is smaller still) and bounds the error of proj by 9e-8 -- points inside a cone with
-    // degenerate multipliers otherwise creep towards f = 0 at a linear rate.
-    if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy || f <= 1e-15) { converged = true; break; }
+    // degenerate multipliers otherwise creep towards f = 0 at a linear rate.  The floor is absolute only for
+    // |y| >= 1: a prediction of tiny norm (|y| < 4.5e-8 has f <= 1e-15 at theta = 0) must still be projected,
+    // because the cosine target only sees the direction of proj.
+    if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy || f <= 1e-15 * fmin(1.0, yy)) { converged = true; break; }
     if constexpr (BAND) {
       // SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
       // the CHKS smoothing of the one-sided clip at scale mu (1/2 at the kink, -> the 0/1 activity D_kk

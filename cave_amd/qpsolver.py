@@ -55,13 +55,28 @@ def _auto_waves(B: int, m: int, d: int, check: bool) -> int:
     instances in flight).  Four waves hold reduced systems up to 32 rows and are only used once a
     status-checked launch has shown the shape fits."""
     if B > 1280:
-        return 1
+        return 1  # reduced systems up to 64 rows, like the 2-wave shape
     ok = _wide_ok.get((m, d))
     if ok is True or (ok is None and check):
         return 4
     return 2
 
 _large_hint: dict[tuple[int, int], tuple[int, int]] = {}  # (m, d) -> (nnz_cap, band_entries) that fitted
+# shapes that have completed a clean status-checked call (any wave count, any tier): only these may be
+# launched unchecked / lazily with what was learnt; `forget_shape` takes a shape out again
+_settled: set[tuple[int, int]] = set()
+
+
+def forget_shape(m: int, d: int) -> None:
+    """Drop everything remembered about (m_max, d).  Called when an unchecked or lazily checked launch
+    reported CAVE_ST_TOO_LARGE: the caches are keyed by shape only, and a later batch of the same shape
+    may hold bigger cones (more reduced rows / non-zeros) than the one that settled it.  The next call
+    for the shape then runs status-checked and walks the tiers again."""
+    key = (int(m), int(d))
+    _tier.pop(key, None)
+    _wide_ok.pop(key, None)
+    _large_hint.pop(key, None)
+    _settled.discard(key)
 
 
 def _large_guess(m: int, d: int) -> tuple[int, int]:
@@ -201,6 +216,8 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
                 tier = _tier[(m, d)] = 2
                 run_large()
             _raise_for_status(status, "solver='hip'")
+            if auto:
+                _settled.add((m, d))
     return out
 
 

@@ -17,9 +17,14 @@ from scipy.optimize import linprog
 
 
 def kkt_certificate(A, y, p, tol=4e-6):
-    A = np.asarray(A, np.float32)
-    keep = np.abs(A).sum(1) > 1e-7  # the reference's padded-row rule (src/cave.py:303)
-    As = sp.csr_matrix(A[keep].astype(np.float64))
+    """A: dense (m, d) array, or a scipy sparse matrix (coordinate-form cones of cave_amd.synth.coo_batch)."""
+    if sp.issparse(A):
+        As = sp.csr_matrix(A, dtype=np.float64)
+        As = As[np.asarray(abs(As).sum(1)).ravel() > 1e-7]
+    else:
+        A = np.asarray(A, np.float32)
+        keep = np.abs(A).sum(1) > 1e-7  # the reference's padded-row rule (src/cave.py:303)
+        As = sp.csr_matrix(A[keep].astype(np.float64))
     y = np.asarray(y, np.float64)
     p = np.asarray(p, np.float64)
     d = y.size
@@ -61,3 +66,9 @@ def assert_projection(A, y, p, tol=4e-6, what=""):
     c = kkt_certificate(A, y, p, tol)
     assert c["dual"] <= tol and c["comp"] <= tol and c["member"], (what, c)
     return c
+
+
+def coo_to_sparse(item, d):
+    """(rows, cols, vals, m) of cave_amd.synth.*_cone_coo -> scipy CSR (m, d)."""
+    r, c, v, m = item
+    return sp.csr_matrix((v.astype(np.float64), (r, c)), shape=(m, d))

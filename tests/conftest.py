@@ -24,4 +24,5 @@ def golden():
         "tsp50": np.load(os.path.join(d, "tsp50.npz")),
         "scipy_defect": np.load(os.path.join(d, "scipy_defect.npz")),
         "large": np.load(os.path.join(d, "large.npz")),
+        "regress": np.load(os.path.join(d, "regress.npz")),
     }

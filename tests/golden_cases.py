@@ -41,3 +41,21 @@ def check_case(impl, golden, file, tag, inner_ratio=0.2):
             if sel.all():
                 assert abs(o["loss"].mean() - g[f"{tag}_{sense}_{vname}_mean"]) <= TOL
                 assert abs(o["loss"].sum() - g[f"{tag}_{sense}_{vname}_sum"]) <= TOL * len(sel)
+
+
+def check_regress(impl, regress):
+    """tests/golden/regress.npz (made by tests/golden/make_regress.py with the reference itself): cones that once
+    hit the Newton iteration cap, and tiny-norm predictions.  Tolerances are RELATIVE to max|y| here (the
+    projection is positively homogeneous and these cases span |y| from 4 down to 2e-12)."""
+    tags = sorted(k[:-2] for k in regress.files if k.endswith("_A"))
+    assert len(tags) >= 9
+    for tag in tags:
+        A, y = regress[f"{tag}_A"], regress[f"{tag}_y"]
+        o = impl(A[None], y[None], MODE_PROJECT, 1.0, 0.0)
+        assert o["status"][0] == 0, (tag, o["status"])
+        assert o["iters"][0] <= 40, (tag, o["iters"])
+        sc = float(np.abs(y).max())
+        assert np.abs(o["proj"][0] - regress[f"{tag}_proj"]).max() <= 4e-6 * sc, tag
+        assert abs(o["rnorm"][0] - regress[f"{tag}_rnorm"]) <= 4e-6 * sc, tag
+        # inside-the-cone decision of src/cave.py:218
+        assert (o["rnorm"][0] < np.float32(1e-7)) == (regress[f"{tag}_rnorm"] < np.float32(1e-7)), tag

@@ -77,17 +77,28 @@ def test_constructor_error_behaviour(monkeypatch):
 
     with pytest.raises(ValueError):
         exactConeAlignedCosine(_model(EPO.MINIMIZE), solver="bogus")
-    with pytest.raises(ValueError):  # the reference's CPU backends are not shipped here
-        exactConeAlignedCosine(_model(EPO.MINIMIZE), solver="nnls")
+    for ref_solver in ("nnls", "clarabel", "apgd"):  # the reference's own backends are not shipped here
+        with pytest.raises(ImportError):
+            exactConeAlignedCosine(_model(EPO.MINIMIZE), solver=ref_solver)
+    with pytest.raises(ImportError):  # the reference's default solver, as in code_sample.py:44
+        innerConeAlignedCosine(_model(EPO.MINIMIZE), processes=1)
+    import inspect
+
+    sig = inspect.signature(innerConeAlignedCosine.__init__)  # src/cave.py:152-163
+    assert list(sig.parameters)[1:] == ["optmodel", "solver", "solver_kwargs", "max_iter", "solve_ratio", "inner_ratio",
+                                        "processes", "reduction", "seed"]
+    assert sig.parameters["solver"].default == "clarabel" and sig.parameters["max_iter"].default == 3
+    sig = inspect.signature(exactConeAlignedCosine.__init__)  # src/cave.py:93-100
+    assert list(sig.parameters)[1:] == ["optmodel", "solver", "solver_kwargs", "processes", "reduction"]
     if not torch.cuda.is_available():
         with pytest.raises(ImportError):  # no device -> loud failure, no fallback (cf. src/cave.py:113-117)
             exactConeAlignedCosine(_model(EPO.MINIMIZE), solver="hip")
     monkeypatch.setattr(_lib, "load", lambda: None)
     with pytest.raises(ValueError):
-        innerConeAlignedCosine(_model(EPO.MINIMIZE), solve_ratio=1.5)
+        innerConeAlignedCosine(_model(EPO.MINIMIZE), solver="hip", solve_ratio=1.5)
     with pytest.raises(ValueError):
-        innerConeAlignedCosine(_model(EPO.MINIMIZE), inner_ratio=-0.1)
-    m = innerConeAlignedCosine(_model(EPO.MINIMIZE), solver_kwargs={"max_iter": 50}, seed=42)
+        innerConeAlignedCosine(_model(EPO.MINIMIZE), solver="hip", inner_ratio=-0.1)
+    m = innerConeAlignedCosine(_model(EPO.MINIMIZE), solver="hip", solver_kwargs={"max_iter": 50}, seed=42)
     assert m.solver_kwargs == {"max_iter": 50} and m.max_iter == 3 and m.solver == "hip"
     # seeded branch RNG: same stream as the reference (src/cave.py:195,201)
     assert abs(m._branch_rng.uniform() - 0.3745401188473625) < 1e-15

@@ -1,0 +1,196 @@
+"""GPU tier, round-2 additions: regression fixtures over every launch shape, the packed store directly against
+the reference's outputs, BASELINE configs 2-4 at their full per-GPU batch sizes on DISTINCT cones with KKT
+certificates, determinism, and the shape caches of the host layer under mixed cone sizes."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from golden_cases import (CASES, MODE_EXACT, MODE_INNER, MODE_PROJECT, check_case, check_regress)
+
+ALL = ("proj", "rnorm", "target", "loss", "grad")
+
+
+def _dense_impl(**kw):
+    import torch
+
+    from cave_amd.qpsolver import cone_op_dense
+
+    def impl(ctrs, costs, mode, sign, inner_ratio):
+        c = torch.tensor(np.asarray(ctrs), device="cuda")
+        p = None if costs is None else torch.tensor(np.asarray(costs), device="cuda")
+        o = cone_op_dense(c, p, mode, sign, inner_ratio, outputs=ALL, **kw)
+        return {k: v.cpu().numpy() for k, v in o.items()}
+    return impl
+
+
+def _packed_impl(waves=0, large=False):
+    import torch
+
+    from cave_amd.dataset import ConeStore
+
+    cache = {}
+
+    def impl(ctrs, costs, mode, sign, inner_ratio):
+        ctrs = np.asarray(ctrs)
+        key = (ctrs.shape, ctrs.tobytes()[:4096], float(ctrs.sum()))
+        if key not in cache:
+            cache.clear()
+            cache[key] = ConeStore.from_dense(torch.tensor(ctrs, device="cuda"), chunk=7)
+        store = cache[key]
+        store.waves = waves
+        ids = torch.arange(len(ctrs), device="cuda")
+        p = None if costs is None else torch.tensor(np.asarray(costs), device="cuda")
+        o = store.cone_op(ids, p, mode, sign, inner_ratio, outputs=ALL)
+        return {k: v.cpu().numpy() for k, v in o.items()}
+    return impl
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_regression_fixtures_dense(golden, waves):
+    check_regress(_dense_impl(waves=waves), golden["regress"])
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_regression_fixtures_packed(golden, waves):
+    check_regress(_packed_impl(waves=waves), golden["regress"])
+
+
+def test_regression_fixtures_large_path(golden):
+    from test_gpu_parity import _force_large
+
+    base = _dense_impl()
+    check_regress(lambda c, y, *a: _force_large(lambda: base(c, y, *a), np.asarray(c)), golden["regress"])
+
+
+@pytest.mark.parametrize("waves", [0, 1, 4])
+@pytest.mark.parametrize("file,tag", CASES)
+def test_packed_store_matches_reference_outputs(golden, file, tag, waves):
+    """ConeStore -> cave_hip_cone_packed directly against the reference's outputs (not via the dense path)."""
+    check_case(_packed_impl(waves=waves), golden, file, tag)
+
+
+def test_two_launches_are_bit_identical():
+    """Fixed summation order everywhere: two launches on the same inputs agree bit for bit on every instance
+    that reports CAVE_ST_OK, in every launch shape, dense and packed."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+    from cave_amd.qpsolver import cone_op_dense
+
+    for ctrs, costs in (synth.tsp_batch(20, 300, seed=5)[:2], synth.sp_batch(5, 5, 200, seed=5)[:2]):
+        c, p = torch.tensor(ctrs, device="cuda"), torch.tensor(costs, device="cuda")
+        store = ConeStore.from_dense(c)
+        ids = torch.arange(len(ctrs), device="cuda")
+        for waves in (1, 2, 4, 8):
+            runs = [cone_op_dense(c, p, MODE_INNER, -1.0, 0.2, waves=waves, check=False, outputs=ALL) for _ in range(2)]
+            ok = (runs[0]["status"] == 0) & (runs[1]["status"] == 0)
+            assert torch.equal(runs[0]["status"], runs[1]["status"]) and bool(ok.any())
+            for k in ALL:
+                assert torch.equal(runs[0][k][ok], runs[1][k][ok]), (waves, k)
+            assert torch.equal(runs[0]["iters"], runs[1]["iters"])
+            store.waves = waves
+            pr = [store.cone_op(ids, p, MODE_INNER, -1.0, 0.2, check=False, outputs=ALL) for _ in range(2)]
+            for k in ALL:
+                assert torch.equal(pr[0][k], pr[1][k]), ("packed", waves, k)
+
+
+def _full_batch(kind, size, B, mode, chunk, n_cert, iters_max):
+    import torch
+
+    from certificate import assert_projection, coo_to_sparse
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+
+    dev = torch.device("cuda")
+    items, costs, _ = synth.coo_batch(kind, size, B, seed=11)
+    d = costs.shape[1]
+    m_max = max(it[3] for it in items)
+    store = ConeStore.from_chunks_lazy(lambda i: synth.densify_on(items[i:i + chunk], d, dev, m_max), list(range(0, B, chunk)))
+    assert store.n == B
+    ids = torch.arange(B, device=dev)
+    pred = torch.tensor(costs, device=dev)
+    o = store.cone_op(ids, pred, MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    assert bool((o["status"] == 0).all())
+    it = o["iters"].cpu().numpy()
+    assert it.max() <= iters_max and it.min() >= 1, (it.min(), it.max())
+    proj, rnorm = o["proj"].cpu().numpy(), o["rnorm"].cpu().numpy()
+    y = -costs
+    res = np.linalg.norm(y.astype(np.float64) - proj, axis=1)
+    assert np.abs(res - rnorm).max() <= 4e-6 * max(1.0, res.max())                     # rnorm is the residual norm
+    assert np.abs(((y - proj).astype(np.float64) * proj).sum(1)).max() <= 2e-5 * (np.linalg.norm(y, axis=1) ** 2).max()
+    for b in np.linspace(0, B - 1, n_cert).astype(int):                               # KKT certificate on a sample
+        assert_projection(coo_to_sparse(items[b], d), y[b], proj[b], what=(kind, size, int(b)))
+    # the loss modes at the same size: finite, in [0, 2], gradient orthogonal to the prediction (cosine loss)
+    o2 = store.cone_op(ids, pred, mode, -1.0, 0.2, outputs=("loss", "grad"))
+    loss, grad = o2["loss"].cpu().numpy(), o2["grad"].cpu().numpy()
+    assert np.isfinite(loss).all() and loss.min() >= -1e-6 and loss.max() <= 2.0 + 1e-6
+    assert np.abs((grad.astype(np.float64) * costs).sum(1)).max() <= 1e-5
+    return store
+
+
+def test_config2_tsp50_full_batch_distinct_cones():
+    """BASELINE configs[2]: TSP-50, per-GPU batch 4096/8 = 512, CaVE Exact."""
+    store = _full_batch("tsp", 50, 512, MODE_EXACT, 64, 16, 30)
+    assert not store.large
+
+
+def test_config3_tsp100_full_batch_distinct_cones():
+    """BASELINE configs[3]: TSP-100, per-GPU batch 2048/4 = 512, QP branch of CaVE Hybrid."""
+    store = _full_batch("tsp", 100, 512, MODE_INNER, 4, 16, 30)
+    assert store.large
+
+
+def test_config4_sp30_full_batch_distinct_cones():
+    """BASELINE configs[4]: shortest path 30x30, per-GPU batch 8192/8 = 1024, CaVE+."""
+    store = _full_batch("sp", (30, 30), 1024, MODE_INNER, 32, 16, 30)
+    assert store.large
+
+
+def test_lazy_check_with_mixed_cone_sizes_under_one_shape():
+    """The launch-shape caches are keyed by (m_max, d) only.  A shape that settled on four waves (<= 32
+    reduced rows) and is later called lazily with bigger cones must not poison training: the failed instances
+    contribute zero loss / gradient, the next call raises, the shape is forgotten, and the call after that
+    (strict again) re-tiers and succeeds."""
+    import torch
+
+    from cave_amd import qpsolver
+    from cave_amd.cave import EPO, exactConeAlignedCosine, flush_checks
+    from cave_amd.qpsolver import HipSolverError
+    from oracle import cave_oracle as O
+
+    class _M:
+        modelSense = EPO.MAXIMIZE
+
+    rng = np.random.default_rng(21)
+    m, d, B = 48, 30, 8
+
+    def cones(rows):
+        A = np.zeros((B, m, d), np.float32)
+        A[:, :rows] = (rng.standard_normal((B, rows, d)) * (rng.random((B, rows, d)) < 0.25)).astype(np.float32)
+        A[:, :rows, 0] = 1.0
+        A[:, :rows, 1] = rng.standard_normal((B, rows))
+        return A
+
+    small, big = cones(20), cones(44)
+    y = rng.standard_normal((B, d)).astype(np.float32)
+    qpsolver.forget_shape(m, d)
+    mod = exactConeAlignedCosine(_M(), solver="hip", solver_kwargs={"check": "lazy"}, reduction="none")
+    p = torch.tensor(y, device="cuda", requires_grad=True)
+    l0 = mod(p, torch.tensor(small, device="cuda"))          # first call for the shape: strict, settles on 4 waves
+    assert qpsolver._wide_ok.get((m, d)) is True and (m, d) in qpsolver._settled
+    want = O.cone_loss(y, O.exact_target(y, small)[0], 1.0)
+    assert np.abs(l0.detach().cpu().numpy() - want).max() <= 2e-6
+    l1 = mod(p, torch.tensor(big, device="cuda"))            # lazy launch with the cached 4-wave shape: does not fit
+    l1.sum().backward()
+    assert torch.isfinite(l1).all() and torch.isfinite(p.grad).all()   # masked, not NaN
+    with pytest.raises(HipSolverError):
+        mod(p, torch.tensor(small, device="cuda"))           # the verdict arrives here ...
+    assert (m, d) not in qpsolver._settled and (m, d) not in qpsolver._wide_ok  # ... and the shape is forgotten
+    flush_checks()
+    l2 = mod(p, torch.tensor(big, device="cuda"))            # strict again: falls back to a shape that fits
+    want = O.cone_loss(y, O.exact_target(y, big)[0], 1.0)
+    assert np.abs(l2.detach().cpu().numpy() - want).max() <= 2e-6
+    flush_checks()

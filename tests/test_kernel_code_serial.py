@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from emul_lib import Emul
-from golden_cases import CASES, MODE_EXACT, MODE_INNER, MODE_PROJECT, check_case
+from golden_cases import CASES, MODE_EXACT, MODE_INNER, MODE_PROJECT, check_case, check_regress
 from oracle import cave_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +31,11 @@ def emul_impl(E):
 @pytest.mark.parametrize("file,tag", CASES)
 def test_serial_kernel_code_matches_reference_outputs(emul, golden, file, tag):
     check_case(emul_impl(emul), golden, file, tag)
+
+
+def test_serial_kernel_code_regression_fixtures(emul, golden):
+    """Former iteration-cap instances and tiny-norm predictions (tests/golden/regress.npz)."""
+    check_regress(emul_impl(emul), golden["regress"])
 
 
 def test_packed_store_equals_dense(emul, golden):
