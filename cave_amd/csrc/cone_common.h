@@ -14,7 +14,9 @@
 #if defined(__HIPCC__)
 #define CAVE_HD __device__ __forceinline__
 #define CAVE_NOINLINE __device__ __noinline__  // own register allocation (cone_band.h)
+#define CAVE_HOSTDEV __host__ __device__ inline
 #else
+#define CAVE_HOSTDEV inline
 #define CAVE_HD inline
 #define CAVE_NOINLINE inline
 #endif
@@ -102,9 +104,10 @@ struct Arena {
     return u >= base && u < base + cap;
   }
   // like get(), but a request that does not fit returns null and leaves the arena untouched
-  template <class T>
+  // (ALIGN: byte alignment of the result relative to the arena base, which is 16-byte aligned in LDS)
+  template <class T, uint32_t ALIGN = 8u>
   CAVE_HD T* try_get(uint32_t n) {
-    uint32_t a = (off + 7u) & ~7u;
+    uint32_t a = (off + (ALIGN - 1u)) & ~(ALIGN - 1u);
     uint64_t e = (uint64_t)a + (uint64_t)n * sizeof(T);
     if (e > top) return nullptr;
     off = (uint32_t)e;

@@ -17,7 +17,11 @@
 //   (smoothed generalised Hessian M W M^T, active-set inner loop on the
 //   quadratic model, exact line search on the true f).  proj = y - res*, rnorm = ||res*||_2.
 #pragma once
+#include <type_traits>
 #include "cone_common.h"
+#if defined(__HIPCC__)
+#include "wave_prims.h"
+#endif
 #include "cone_band.h"
 
 namespace cave {
@@ -434,6 +438,164 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
   c.sync();
 }
 
+// ------------------------------------------------------------ small +-1 cones on ONE wave ("lite" form)
+//
+// One Newton iteration is a chain of short dependent phases.  Measured on TSP-20 (p ~ 24 reduced rows, d = 190,
+// ~530 non-zeros; tools/diag/run_stamps.py, tools/micro/lite_bench.hip): 32-36 k cycles per iteration, the same
+// on one wave and on four.  The time goes into dependent LDS round trips (~70 cycles each: row pointer -> entry
+// -> operand, once per entry of a dynamic-length loop) and into instruction issue (~5 cycles per instruction
+// for a lone wave), not into barriers or arithmetic.  For cones with +-1 entries, at most 32 reduced rows, at
+// most 8 entries per column, at most 1024 non-zeros and d <= 256 the one-wave kernels therefore run the solver
+// (SoloCtx, ctx_block.h) over two regular index structures built once per instance, in which every load of a
+// phase is independent of the others and NOTHING is predicated or branched on inside a phase:
+//   ell   [d][8] u16   the column of coordinate k: reduced row | sign << 15; unused slots hold row 32, a dummy
+//                      multiplier that is always 0 (ONE 16-byte LDS read per coordinate; M^T x, Hessian updates)
+//   csr16 [chn8 / 8][64][8] u16   CSR entry e = lane * chn8 + c: col | sign << 15; unused slots hold column d,
+//                      a dummy coordinate whose residual is always 0.  M x by PREFIX SUMS: each lane adds up its
+//                      contiguous run, a wave scan turns the lane totals into global prefixes P(e), and row i is
+//                      P(last entry of i) - P(last entry of i - 1): two LDS reads per row, no segment logic.
+struct LiteCone {
+  const uint32_t* ell;    // [4 * d]            (16-byte aligned)
+  const uint32_t* csr16;  // [4 * 64 * chn8 / 8 ... ] = 32 * chn8 words (16-byte aligned)
+  double* pfx;            // [64 * chn8 + 1]    prefix sums, slot c * 64 + lane; the last slot stays 0
+  const uint16_t* pend;   // [p + 1]            pend[i + 1]: slot of the last entry of row i (pend[0]: the zero slot)
+  int chn8;               // CSR entries per lane: 8 or 16
+  int cmax;               // largest column count
+};
+static constexpr int kLiteMaxRows = 32, kLiteMaxD = 256, kLiteMaxCol = 8, kLiteMaxChunk = 16;
+static constexpr uint32_t kLiteDummyRow = 32;
+
+CAVE_HOSTDEV uint32_t lite_lds_bytes(int d, uint32_t nnz) {
+  const uint32_t chn8 = nnz <= 512u ? 8u : 16u;
+  return 16u * (uint32_t)d + 128u * chn8 + 8u * (64u * chn8 + 1u) + 2u * 34u + 64u;
+}
+
+// Build the lite structures (all threads of the context).  Returns false when the cone does not qualify or the
+// arena has no room; the caller then runs the general solver.
+template <class C>
+CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
+  const int NT = C::NT;
+  const int d = v.d, p = v.p;
+  if (!v.pm1 || p < 1 || p > kLiteMaxRows || d > kLiteMaxD) return false;
+  const uint32_t nnz = v.mptr[p];
+  if (nnz == 0u || nnz > 64u * (uint32_t)kLiteMaxChunk) return false;
+  const uint32_t chn8 = nnz <= 512u ? 8u : 16u;
+  uint32_t* ell = ar.try_get<uint32_t, 16u>(4u * (uint32_t)d);
+  uint32_t* csr16 = ell ? ar.try_get<uint32_t, 16u>(32u * chn8) : nullptr;
+  double* pfx = csr16 ? ar.try_get<double>(64u * chn8 + 1u) : nullptr;
+  uint16_t* pend = pfx ? ar.try_get<uint16_t>(34u) : nullptr;
+  if (!pend) return false;
+  // columns -> ELL rows of 8 (unused slots: the dummy row)
+  uint32_t over = 0;
+  double cm = 0.0;
+  for (int k = c.tid(); k < d; k += NT) {
+    const uint32_t lo = v.cptr[k], cnt = v.cptr[k + 1] - lo;
+    over += cnt > (uint32_t)kLiteMaxCol ? 1u : 0u;
+    cm = fmax(cm, (double)cnt);
+    uint32_t x[8];
+#pragma unroll
+    for (uint32_t e = 0; e < 8; ++e) x[e] = v.cvar[lo + (e < cnt ? e : 0u)];  // unconditional loads
+#pragma unroll
+    for (uint32_t e = 0; e < 8; ++e) x[e] = e < cnt ? x[e] : kLiteDummyRow;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ell[4 * k + q] = x[2 * q] | (x[2 * q + 1] << 16);
+  }
+  // CSR entries, 8 per 16-byte word group: entry e = lane * chn8 + c at u16 index ((c / 8) * 64 + lane) * 8 + c % 8.
+  // The stored sign is that of -M (the gradient is g = -M rc).
+  uint16_t* c16 = reinterpret_cast<uint16_t*>(csr16);
+  for (uint32_t idx = c.tid(); idx < 64u * chn8; idx += NT) {
+    const uint32_t g8 = idx / 512u, ln = (idx / 8u) & 63u, u = idx & 7u;
+    const uint32_t e = ln * chn8 + g8 * 8u + u;
+    const uint32_t x = v.mcol[e < nnz ? e : 0u];
+    c16[idx] = (uint16_t)(e < nnz ? (x ^ 0x8000u) : (uint32_t)d);
+  }
+  // where the prefix of each row's last entry will be found
+  for (int i = c.tid(); i <= p; i += NT) {
+    const uint32_t hi = v.mptr[i];  // one past the last entry of row i - 1
+    uint32_t slot = 64u * chn8;     // the zero slot: nothing before the first row
+    if (i > 0 && hi > 0u) {
+      const uint32_t e = hi - 1u;
+      slot = (e % chn8) * 64u + e / chn8;
+    }
+    pend[i] = (uint16_t)slot;
+  }
+  if (c.tid() == 0) pfx[64u * chn8] = 0.0;
+  over = c.reduce_add_u32(over);
+  L.cmax = (int)c.reduce_max(cm);
+  c.sync();
+  if (over) return false;
+  L.ell = ell; L.csr16 = csr16; L.pfx = pfx; L.pend = pend; L.chn8 = (int)chn8;
+  return true;
+}
+
+#if defined(__HIPCC__)
+// +-x with the sign taken from bit 15 of a 16-bit entry (no select: the sign bit is xor-ed in)
+__device__ __forceinline__ double lite_signed(double x, uint32_t entry) {
+  return __hiloint2double(__double2hiint(x) ^ (int)((entry & 0x8000u) << 16), __double2loint(x));
+}
+// inclusive prefix sum across the 64 lanes (fixed tree)
+__device__ __forceinline__ double wave_inclusive_scan_f64(double v) {
+  v += dpp_f64<0x111, 0xf>(0.0, v);  // row_shr:1
+  v += dpp_f64<0x112, 0xf>(0.0, v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(0.0, v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(0.0, v);  // row_shr:8
+  v += dpp_f64<0x142, 0xa>(0.0, v);  // row_bcast:15 -> rows 1,3
+  v += dpp_f64<0x143, 0xc>(0.0, v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// (M^T x)[k] for one coordinate: one 16-byte index read, 8 independent operand reads (x[32] = 0 is the dummy)
+__device__ __forceinline__ double lite_col_dot(const LiteCone& L, int k, const double* x) {
+  const uint4 t = *reinterpret_cast<const uint4*>(L.ell + 4 * k);
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+  double val[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) val[e] = x[(w[e >> 1] >> ((e & 1) * 16)) & 63u];
+  double acc = 0.0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc += lite_signed(val[e], w[e >> 1] >> ((e & 1) * 16));
+  return acc;
+}
+
+// out[k] = base[k] + sgn * (M^T x)[k] for the coordinates of this wave (x: [33] doubles in LDS, x[32] = 0)
+template <class C>
+__device__ __forceinline__ void lite_gather(C& c, const LiteCone& L, int d, const float* base, const double* x, double sgn,
+                                            double* out) {
+  for (int k = c.tid(); k < d; k += C::NT) out[k] = (base ? (double)base[k] : 0.0) + sgn * lite_col_dot(L, k, x);
+  c.sync();
+}
+
+// g = -M rc by prefix sums (rc[d] = 0 is the dummy coordinate)
+template <class C>
+__device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, const double* rc, double* g) {
+  const int lane = c.lane_id();
+  double pre[kLiteMaxChunk];
+  double run = 0.0;
+#pragma unroll
+  for (int g8 = 0; g8 < kLiteMaxChunk / 8; ++g8) {
+    if (g8 * 8 < L.chn8) {  // wave-uniform; the loads of a group are all issued before the first add
+      const uint4 t = *reinterpret_cast<const uint4*>(L.csr16 + 4 * (g8 * 64 + lane));
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+      double val[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) val[u] = rc[(w[u >> 1] >> ((u & 1) * 16)) & 0x7fffu];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        run += lite_signed(val[u], w[u >> 1] >> ((u & 1) * 16));
+        pre[g8 * 8 + u] = run;
+      }
+    }
+  }
+  const double base = wave_inclusive_scan_f64(run) - run;  // sum of the lanes before this one
+#pragma unroll
+  for (int cc = 0; cc < kLiteMaxChunk; ++cc)
+    if (cc < L.chn8) L.pfx[cc * 64 + lane] = base + pre[cc];
+  c.sync();
+  if (lane < p) g[lane] = L.pfx[L.pend[lane + 1]] - L.pfx[L.pend[lane]];
+  c.sync();
+}
+#endif  // __HIPCC__
+
 // phi'(alpha) and phi''(alpha) of phi(alpha) = 1/2 || Pi(r - alpha q) ||^2
 template <class C>
 CAVE_HD void dphi(C& c, const SolveView& v, const double* r, const double* q, double alpha, double* d1, double* d2) {
@@ -492,6 +654,25 @@ CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
   return alpha;
 }
 
+// does the context carry the lite index structures (SoloCtx)?
+template <class C, class = void> struct ctx_lite : std::false_type {};
+template <class C> struct ctx_lite<C, std::void_t<decltype(C::LITE)>> : std::bool_constant<C::LITE> {};
+
+template <class C, bool PM1>
+CAVE_HD void gradient_any(C& c, const SolveView& v, const double* rc, double* g) {
+#if defined(__HIPCC__)
+  if constexpr (ctx_lite<C>::value) { lite_gradient(c, c.lite, v.p, rc, g); return; }
+#endif
+  gradient<C, PM1>(c, v, rc, g);
+}
+template <class C, bool PM1>
+CAVE_HD void gather_any(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
+#if defined(__HIPCC__)
+  if constexpr (ctx_lite<C>::value) { lite_gather(c, c.lite, v.d, base, th, sgn, out); return; }
+#endif
+  gather_mt<C, PM1>(c, v, base, th, sgn, out);
+}
+
 // One Newton step = exact minimisation of the local quadratic model over the
 // non-negativity constraints by a primal active-set inner loop (ratio test to
 // the first blocking bound, fix it at zero, re-solve on the smaller face — the
@@ -540,7 +721,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   CAVE_T0();
   for (; p > 0 && it < max_iter; ++it, cap07 *= 0.7, sched01 *= 0.1) {
     // gradient g = -M Pi(r) and projected-gradient norm
-    gradient<C, PM1>(c, v, rc, w.g);
+    gradient_any<C, PM1>(c, v, rc, w.g);
     // Zig-zag extrapolation.  On degenerate cones (duplicated generators, y inside the cone) the iteration can
     // settle into a two-cycle of active sets and crawl along a valley at a linear rate.  From iteration 10 on,
     // every second iteration first minimises f exactly along theta - theta(two iterations ago), the valley
@@ -558,7 +739,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         amax = -c.reduce_max(-amax);
         c.sync();
         if (psi0 < 0.0 && amax > 0.0) {
-          gather_mt<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
+          gather_any<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
           const double alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
           for (int i = c.tid(); i < p; i += NT) {
             double t = theta[i] + alpha * w.dv[i];
@@ -566,9 +747,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
             theta[i] = t;
           }
           c.sync();
-          gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+          gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
           f = refresh_clipped(c, v, r, rc);
-          gradient<C, PM1>(c, v, rc, w.g);
+          gradient_any<C, PM1>(c, v, rc, w.g);
         }
       }
       for (int i = c.tid(); i < p; i += NT) w.told[i] = theta[i];
@@ -704,6 +885,35 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           else wn = t > 0.0 ? 1.0f : 0.0f;
         }
         const float wo = w.wold[k];
+#if defined(__HIPCC__)
+        if constexpr (ctx_lite<C>::value) {
+          // lite form: the column comes in one 16-byte read; all lanes walk the (e1, e2 <= e1) pairs together and
+          // stop at the longest column that changed.  Only the LOWER triangle of H is kept (columns are sorted
+          // by reduced row, so e2 < e1 means b < a); gj_solve<.., LOWER> reads the rest transposed.
+          const bool changed = wn != wo;
+          if (__ballot(changed) == 0ull) continue;
+          if (changed) w.wold[k] = wn;
+          const double dw = (double)wn - (double)wo;
+          const uint4 t4 = *reinterpret_cast<const uint4*>(c.lite.ell + 4 * k);
+          const uint32_t cw[4] = {t4.x, t4.y, t4.z, t4.w};
+          static_for<0, 8>([&](auto e1c) {
+            constexpr int e1 = decltype(e1c)::value;
+            const uint32_t x1 = (cw[e1 >> 1] >> ((e1 & 1) * 16)) & 0xffffu;
+            const bool on1 = changed && (x1 & 0x7fffu) != kLiteDummyRow;
+            if (e1 < c.lite.cmax && __ballot(on1) != 0ull) {  // no loads inside: branching costs nothing here
+              const uint32_t a = x1 & 0x7fffu;
+              const double va = (x1 & 0x8000u) ? -dw : dw;
+              if (on1) c.atomic_add_f64(&w.H[a * ldh + a], dw);
+              static_for<0, e1>([&](auto e2c) {
+                constexpr int e2 = decltype(e2c)::value;
+                const uint32_t x2 = (cw[e2 >> 1] >> ((e2 & 1) * 16)) & 0xffffu;
+                if (on1) c.atomic_add_f64(&w.H[a * ldh + (x2 & 0x7fffu)], (x2 & 0x8000u) ? -va : va);
+              });
+            }
+          });
+          continue;
+        }
+#endif
         if (wn == wo) continue;
         w.wold[k] = wn;
         const double dw = (double)wn - (double)wo;
@@ -780,7 +990,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
               const int j0 = i - w.bw > 0 ? i - w.bw : 0, j1 = i + w.bw < p - 1 ? i + w.bw : p - 1;
               for (int j = j0; j <= j1; ++j) s += band_at(w.H, ldh, i, j) * w.step[j];
             } else {
-              for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
+              if constexpr (ctx_lite<C>::value) {  // lower triangle only
+                for (int j = 0; j <= i; ++j) s += w.H[i * ldh + j] * w.step[j];
+                for (int j = i + 1; j < p; ++j) s += w.H[j * ldh + i] * w.step[j];
+              } else {
+                for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
+              }
             }
             rhs[i] = s;  // rhs is dead until the next inner round
           }
@@ -836,6 +1051,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           rk[j] = r[k];
           uk[j] = v.usign[k];
           double q = 0.0;
+#if defined(__HIPCC__)
+          if constexpr (ctx_lite<C>::value) {
+            q = lite_col_dot(c.lite, k, w.dv);
+          } else
+#endif
           for (uint32_t e = v.cptr[k]; e < v.cptr[k + 1]; ++e) {
             uint32_t var;
             double val;
@@ -875,7 +1095,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       }
       update_theta(c, v, theta, tc, w.dv, alpha, amax);
       if (fresh) {
-        gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+        gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
         fn = refresh_clipped(c, v, r, rc);
       } else {
         fn = 0.5 * c.reduce_sum(acc);
@@ -883,12 +1103,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       }
       CAVE_ACC(8);
     } else {
-      gather_mt<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
+      gather_any<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
       CAVE_ACC(6);
       alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
       update_theta(c, v, theta, tc, w.dv, alpha, amax);
       CAVE_ACC(7);
-      if ((it & 7) == 7) gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+      if ((it & 7) == 7) gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
       else {
         for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
         c.sync();
@@ -915,7 +1135,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   }
   // final residual straight from theta (the iteration updated r incrementally), clipped for the epilogue
   if (p > 0) {
-    gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+    gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
     f = refresh_clipped(c, v, r, rc);
   }
   for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];

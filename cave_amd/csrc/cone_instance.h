@@ -192,13 +192,15 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
 #endif
     } else {
       if (p > C::PMAX) return ST_TOO_LARGE;
-      w.rc = ar.get<double>(d);
+      // rc[d], theta[32] and dv[32] are the always-zero dummies of the lite index structures (cone_core.h)
+      const uint32_t pg = pp < 33u ? 33u : pp;
+      w.rc = ar.get<double>((uint32_t)d + 1u);
       w.wold = ar.get<float>(d);
-      w.theta = ar.get<double>(pp);
+      w.theta = ar.get<double>(pg);
       w.ttry = ar.get<double>(pp);
       w.told = ar.get<double>(pp);
       w.g = ar.get<double>(pp);
-      w.dv = ar.get<double>(pp);
+      w.dv = ar.get<double>(pg);
       w.g2 = ar.get<double>(pp);
       w.step = ar.get<double>(pp);
       w.ldh = p | 1;
@@ -210,13 +212,42 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     uint8_t* lflag = ar.get<uint8_t>(pp);
     uint32_t* llist = ar.get<uint32_t>(pp);
     if (ar.ovf) return ST_TOO_LARGE;
+    if constexpr (!LARGE) {
+      if (c.tid() == 0) {
+        w.rc[d] = 0.0;
+        if (p <= 32) { w.theta[32] = 0.0; w.dv[32] = 0.0; }
+      }
+    }
     for (int i = c.tid(); i < p; i += C::NT) lflag[i] = (uint8_t)((v.mptr[i + 1] - v.mptr[i]) > kLongRow ? 1 : 0);
     c.sync();
     SolveView vv = v;
     vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
     vv.longrow = llist;
     c.sync();
-    SolveResult r = solve_cone<C, LARGE>(c, vv, w, max_iter, 1e-11);
+    SolveResult r;
+    bool lite = false;
+#if defined(__HIPCC__)
+    if constexpr (!LARGE && C::NWAVES == 1) {
+      // small +-1 cone on a one-wave workgroup: Newton iteration over the lite index structures (cone_core.h).
+      // (Only the one-wave kernels carry this path: it wants ~200 VGPRs, and inlined into the 4-wave kernels,
+      // whose residency rests on a 128-VGPR budget, it cost 650 bytes of scratch per lane.)
+      LiteCone L;
+      lite = lite_build(c, ar, vv, L);
+      if (lite) {
+        SoloCtx<32, 4> sc;
+        sc.lane = c.lane_id();
+        sc.lite = L;
+#ifdef CAVE_STAMPS
+        sc.st = c.st;
+#endif
+        r = solve_cone_impl<SoloCtx<32, 4>, true, false>(sc, vv, w, max_iter, 1e-11);
+#ifdef CAVE_STAMPS
+        c.st[13] += 1000000;  // diagnostic marker: the lite path ran
+#endif
+      }
+    }
+#endif
+    if (!lite) r = solve_cone<C, LARGE>(c, vv, w, max_iter, 1e-11);
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
@@ -465,7 +496,9 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
                    + (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d));  // signatures | fill
   uint64_t vecs = 2 * align8u(4 * d);                                                            // y, avg
   uint64_t solve = 3 * align8u(8 * d) + align8u(4 * d)                                           // res, tvec/q, rc, wold
-                   + 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p);  // theta..step, told, H, act, long rows
+                   + 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p)  // theta..step, told, H, act, long rows
+                   + 8 + 2 * 8 * 33;                                                              // dummy slots of the lite form
+  if (pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)nnzM);  // lite index structures
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
@@ -531,7 +564,11 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(4 * (p + 1)) + align8u(p);                                               // mptr, vkind
   s += 2 * (align8u(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : align8u(4 * (int64_t)max_nnz)));  // CSR + CSC (+ values)
   s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
-  s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256;
+  s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256 + 8 + 2 * 8 * 33;
+  if (all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
+    const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)max_nnz);
+    if (with_lite <= kMaxLds) s = with_lite;
+  }
   if (s > kMaxLds) return -1;
   return (int32_t)s;
 }

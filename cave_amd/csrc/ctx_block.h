@@ -11,8 +11,47 @@
 // Every method must be called by all threads of the workgroup from uniform control flow.
 #pragma once
 #include "wave_prims.h"
+#include "ctx_wave.h"
 
 namespace cave {
+
+// SoloCtx — the Newton iteration of a SMALL +-1 cone on ONE wave (wave 0 of a multi-wave workgroup, the other
+// waves parked at the workgroup barrier that follows; or the only wave of a one-wave workgroup), over the
+// "lite" index structures of cone_core.h.  A cross-lane reduction is a DPP tree with no LDS slot and no
+// barrier, and a phase boundary is free: the LDS operations of one wave execute in issue order, so only the
+// compiler has to be kept from moving memory operations across it.
+template <int PMAX_, int KREG_>
+struct SoloCtx {
+  static constexpr int NT = 64;
+  static constexpr int TEAM = 4;
+  static constexpr int PMAX = PMAX_;
+  static constexpr int KREG = KREG_;
+  static constexpr int NWAVES = 1;
+  static constexpr int WL = 64;
+  static constexpr bool LITE = true;
+  int lane;
+  LiteCone lite;
+#ifdef CAVE_STAMPS
+  unsigned long long* st;
+#endif
+  __device__ __forceinline__ int tid() const { return lane; }
+  __device__ __forceinline__ int wave_id() const { return 0; }
+  __device__ __forceinline__ int lane_id() const { return lane; }
+  __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
+  __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
+  __device__ __forceinline__ void sync() const { asm volatile("" ::: "memory"); }
+  __device__ __forceinline__ double reduce_sum(double v) const { return wave_sum_f64(v); }
+  __device__ __forceinline__ void reduce_sum2(double& a, double& b) const { a = wave_sum_f64(a); b = wave_sum_f64(b); }
+  __device__ __forceinline__ double reduce_max(double v) const { return wave_max_f64(v); }
+  __device__ __forceinline__ uint32_t reduce_add_u32(uint32_t v) const { return wave_sum_u32(v); }
+  __device__ __forceinline__ double team_reduce_sum(double v) const { return quad_sum_f64(v); }
+  __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }
+  // H holds its lower triangle only in the lite form
+  __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
+                                            double reg_rel, double* dv) const {
+    gj_solve<(PMAX < 32 ? PMAX : 32), true>(lane, H, ldh, g, act, p, reg_rel, dv);
+  }
+};
 
 // WIDE: launched with a 256-VGPR budget even at 4 waves (the large-cone kernels): deeper scan prefetch
 template <int NW, bool WIDE = false>
@@ -168,7 +207,7 @@ struct BlockCtx {
   // wave 0 solves in registers; the caller's sync() publishes dv to the other waves
   __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                             double reg_rel, double* dv) const {
-    if (wave == 0) gj_solve<PMAX>(lane, H, ldh, g, act, p, reg_rel, dv);
+    if (wave == 0) gj_solve_small<PMAX>(lane, H, ldh, g, act, p, reg_rel, dv);
   }
 
   // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns

@@ -2,6 +2,7 @@
 // (ctx_wave.h: one wave per instance; ctx_block.h: NW cooperating waves per instance).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "cone_common.h"
 
 namespace cave {
@@ -75,12 +76,85 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t inc) {
   return inc;
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [LO, HI)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
 // Solve the p x p system whose free rows are rows of (H + delta*I) and whose
 // fixed rows (act) are identity rows:   H_FF x_F + H_FA x_A = rhs_F,  x_A = rhs_A.
-// ONE wave: lane i keeps row i of [H | rhs] in registers; Gauss-Jordan elimination,
+// ONE wave: lane i keeps row i of [H | rhs] in registers; Gauss-Jordan elimination with the pivot row
+// normalised (lane k uses the multiplier (piv - 1) / piv, so x = the right-hand-side column at the end),
 // pivot row broadcast with v_readlane (no LDS traffic, no barriers).
-template <int PM>
+//
+// What a pivot costs on one wave (measured, tools/micro/gj_bench.hip, prim_bench.hip): a dependent chain of
+// ~140 cycles (v_readlane pair ~19, v_rcp_f64 ~17, each dependent f64 fma ~5.5) + ~15 cycles per remaining
+// column (two v_readlane + one v_fma_f64).  Hence:
+//   * the pivot row is read G columns at a time: the SGPR results of a batch are all written before the first
+//     v_fma reads one, so the VALU-writes-SGPR hazard costs no s_nop (24.8 -> ~15 cycles per column);
+//   * v_rcp_f64 (~24 bits) + ONE Newton step (~48 bits): the Newton direction of the outer iteration needs no
+//     more, and an exact line search follows;
+//   * nothing is selected between the pivot and its reciprocal: a non-positive / NaN pivot (numerically
+//     dependent row) is clamped for the reciprocal and masked out of the multiplier: the row is skipped, x_k = 0.
+// LOWER: only the lower triangle of H is valid (H[i][j], j <= i); the upper part is read transposed.
+template <int PM, bool LOWER = false, int G = 4>
 __device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh, const double* rhs,
+                                              const uint8_t* act, int p, double reg_rel, double* dv) {
+  const bool live = lane < p;
+  const bool my_act = live && act[lane] != 0;
+  double diag0 = (live && !my_act) ? H[lane * ldh + lane] : 0.0;
+  const double maxdiag = wave_max_f64(diag0);
+  const double reg = reg_rel * maxdiag;
+  double h[PM + 1];  // h[PM]: right-hand side
+#pragma unroll
+  for (int j = 0; j < PM; ++j) {
+    double v = 0.0;
+    if (j < p) {
+      if (live && !my_act) v = (LOWER && j > lane) ? H[j * ldh + lane] : H[lane * ldh + j];
+      if (j == lane) v = my_act ? 1.0 : v + reg;
+    } else if (j == lane) v = 1.0;  // rows beyond p: identity
+    h[j] = v;
+  }
+  h[PM] = live ? rhs[lane] : 0.0;
+  uint64_t deadmask = 0;  // pivots that were not positive
+  static_for<0, PM>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (k < p) {
+      const double piv = readlane_f64(h[k], k);
+      const bool ok = piv > 1e-300;
+      const double pv = fmax(piv, 1e-300);
+      double inv = __builtin_amdgcn_rcp(pv);
+      inv = fma(fma(-pv, inv, 1.0), inv, inv);
+      deadmask |= ok ? 0ull : (1ull << k);
+      const double num = ok ? h[k] - ((lane == k) ? 1.0 : 0.0) : 0.0;
+      const double fac = num * inv;
+      constexpr int NCOL = PM - k;  // columns k+1 .. PM (PM = right-hand side); columns >= p hold zeros
+      static_for<0, (NCOL + G - 1) / G>([&](auto gc) {
+        constexpr int j0 = k + 1 + decltype(gc)::value * G;
+        double sv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (j0 + g <= PM) sv[g] = readlane_f64(h[j0 + g], k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (j0 + g <= PM) h[j0 + g] -= fac * sv[g];
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  });
+  if (live) dv[lane] = ((deadmask >> lane) & 1ull) ? 0.0 : h[PM];
+}
+
+// The round-1 form of the same elimination: one column at a time (v_readlane pair, hazard nop, v_fma), explicit
+// diagonal.  ~20 % slower than gj_solve_regs but it needs fewer registers, which is what counts in the 4-wave
+// kernels (128-VGPR budget: with the batched form they spill ~70 registers).
+template <int PM>
+__device__ __forceinline__ void gj_solve_regs_small(int lane, const double* H, int ldh, const double* rhs,
                                               const uint8_t* act, int p, double reg_rel, double* dv) {
   const bool live = lane < p;
   const bool my_act = live && act[lane] != 0;
@@ -122,21 +196,38 @@ __device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh
   if (live) dv[lane] = dead ? 0.0 : b / diag;
 }
 
-// size-specialised dispatch; PLIM bounds the register footprint (2*PM VGPRs for the row)
 template <int PLIM>
+__device__ __forceinline__ void gj_solve_small(int lane, const double* H, int ldh, const double* g, const uint8_t* act,
+                                               int p, double reg_rel, double* dv) {
+  if (p <= 8) gj_solve_regs_small<8>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 16) gj_solve_regs_small<16>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 20) gj_solve_regs_small<20>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 24) gj_solve_regs_small<24>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 28) gj_solve_regs_small<28>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 32) gj_solve_regs_small<32>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if constexpr (PLIM > 32) {
+    if (p <= 40) gj_solve_regs_small<40>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 48) gj_solve_regs_small<48>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 56) gj_solve_regs_small<56>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else gj_solve_regs_small<64>(lane, H, ldh, g, act, p, reg_rel, dv);
+  }
+}
+
+// size-specialised dispatch; PLIM bounds the register footprint (2*PM + 2 VGPRs for the row)
+template <int PLIM, bool LOWER = false>
 __device__ __forceinline__ void gj_solve(int lane, const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                          double reg_rel, double* dv) {
-  if (p <= 8) gj_solve_regs<8>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 16) gj_solve_regs<16>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 20) gj_solve_regs<20>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 24) gj_solve_regs<24>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 28) gj_solve_regs<28>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 32) gj_solve_regs<32>(lane, H, ldh, g, act, p, reg_rel, dv);
+  if (p <= 8) gj_solve_regs<8, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 16) gj_solve_regs<16, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 20) gj_solve_regs<20, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 24) gj_solve_regs<24, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 28) gj_solve_regs<28, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 32) gj_solve_regs<32, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
   else if constexpr (PLIM > 32) {
-    if (p <= 40) gj_solve_regs<40>(lane, H, ldh, g, act, p, reg_rel, dv);
-    else if (p <= 48) gj_solve_regs<48>(lane, H, ldh, g, act, p, reg_rel, dv);
-    else if (p <= 56) gj_solve_regs<56>(lane, H, ldh, g, act, p, reg_rel, dv);
-    else gj_solve_regs<64>(lane, H, ldh, g, act, p, reg_rel, dv);
+    if (p <= 40) gj_solve_regs<40, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 48) gj_solve_regs<48, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 56) gj_solve_regs<56, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else gj_solve_regs<64, LOWER>(lane, H, ldh, g, act, p, reg_rel, dv);
   }
 }
 

@@ -1,0 +1,99 @@
+// Micro-benchmark: cycles of the pieces of one Newton iteration on ONE wave, on real TSP-20 cones
+// (dense input -> the kernels' own scan / build / lite_build, then each piece timed with s_memtime).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../include/cave_hip.h"
+#include "../../cave_amd/csrc/cone_common.h"
+#include "../../cave_amd/csrc/cone_core.h"
+#include "../../cave_amd/csrc/ctx_wave.h"
+#include "../../cave_amd/csrc/ctx_block.h"
+#include "../../cave_amd/csrc/cone_instance.h"
+using namespace cave;
+
+#define NSLOT 12
+__global__ __launch_bounds__(64) void k(const float* ctrs, const float* pred, int m, int d, uint32_t cap, uint32_t lds,
+                                        unsigned long long* out, int reps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WaveCtx c; c.init(smem);
+  Arena ar; ar.init(smem, lds);
+  ConeBuild cb;
+  const int b = blockIdx.x;
+  int32_t st = scan_and_build<WaveCtx, false>(c, ar, cb, ctrs + (size_t)b * m * d, m, d, cap);
+  if (st != ST_OK) { if (threadIdx.x == 0) out[b * NSLOT] = 999999999ull; return; }
+  float* y = ar.get<float>(d);
+  for (int kx = c.tid(); kx < d; kx += 64) y[kx] = -pred[(size_t)b * d + kx];
+  ar.release_top();
+  SolveView v = view_of(cb);
+  const int p = v.p;
+  double* res = ar.get<double>(d + 1); double* rc = ar.get<double>(d + 1); double* q = ar.get<double>(d + 1);
+  double* theta = ar.get<double>(40); double* g = ar.get<double>(40); double* dv = ar.get<double>(40);
+  double* H = ar.get<double>(33 * 33); uint8_t* act = ar.get<uint8_t>(40); float* wold = ar.get<float>(d);
+  LiteCone L;
+  c.sync();
+  unsigned long long t[NSLOT + 1];
+  t[0] = __builtin_amdgcn_s_memtime();
+  bool ok = lite_build(c, ar, v, L);
+  t[NSLOT] = __builtin_amdgcn_s_memtime();
+  if (!ok) { if (threadIdx.x == 0) out[b * NSLOT] = 888888888ull; return; }
+  SoloCtx<32, 4> sc; sc.lane = threadIdx.x; sc.lite = L;
+  for (int kx = c.tid(); kx <= d; kx += 64) { res[kx] = kx < d ? y[kx] : 0.0; rc[kx] = kx < d ? clip_unit(y[kx], v.usign[kx]) : 0.0; }
+  for (int i = c.tid(); i < 40; i += 64) { theta[i] = i < 32 ? 0.01 * i : 0.0; dv[i] = i < 32 ? 0.02 * i - 0.1 : 0.0; act[i] = 0; }
+  for (int i = c.tid(); i < 33 * 33; i += 64) H[i] = (i % 34 == 0) ? 20.0 : 0.25;
+  c.sync();
+  t[1] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) lite_gradient(sc, L, p, rc, g);
+  t[2] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) lite_gather(sc, L, d, y, theta, -1.0, res);
+  t[3] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) { double f = refresh_clipped(sc, v, res, rc); if (f < -1.0) g[0] = f; }
+  t[4] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) { sc.solve_spd(H, 33, g, act, p, 1e-12, dv); sc.sync(); }
+  t[5] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) gradient<SoloCtx<32, 4>, true>(sc, v, rc, g);   // general form, for comparison
+  t[6] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) gather_mt<SoloCtx<32, 4>, true>(sc, v, y, theta, -1.0, res);
+  t[7] = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) { double a = sc.reduce_sum(g[threadIdx.x & 31]); double bb = sc.reduce_max(dv[threadIdx.x & 31]); if (a + bb == 1.2345) g[1] = a; }
+  t[8] = __builtin_amdgcn_s_memtime();
+  // cross-check: lite vs general results
+  lite_gradient(sc, L, p, rc, g); double gl = threadIdx.x < p ? g[threadIdx.x] : 0.0;
+  gradient<SoloCtx<32, 4>, true>(sc, v, rc, g); double gg = threadIdx.x < p ? g[threadIdx.x] : 0.0;
+  double err = sc.reduce_max(fabs(gl - gg));
+  lite_gather(sc, L, d, y, theta, -1.0, res); double r1 = threadIdx.x < d ? res[threadIdx.x] : 0.0;
+  gather_mt<SoloCtx<32, 4>, true>(sc, v, y, theta, -1.0, res); double r2 = threadIdx.x < d ? res[threadIdx.x] : 0.0;
+  double err2 = sc.reduce_max(fabs(r1 - r2));
+  if (threadIdx.x == 0 && (err > 1e-12 || err2 > 1e-12)) printf("MISMATCH block %d: gradient %.3e gather %.3e\n", b, err, err2);
+  if (threadIdx.x == 0) {
+    out[b * NSLOT + 0] = t[NSLOT] - t[0];
+    for (int i = 1; i < 8; ++i) out[b * NSLOT + i] = (t[i + 1] - t[i]) / reps;
+    out[b * NSLOT + 8] = p; out[b * NSLOT + 9] = L.chn8; out[b * NSLOT + 10] = L.cmax; out[b * NSLOT + 11] = v.mptr[p];
+  }
+}
+
+int main(int argc, char** argv) {
+  // input: a binary file written by tools/micro/make_tsp20.py: int32 B, m, d then ctrs [B,m,d] f32, pred [B,d] f32
+  FILE* f = fopen(argc > 1 ? argv[1] : "tsp20.bin", "rb");
+  if (!f) { printf("no input\n"); return 1; }
+  int hdr[3]; fread(hdr, 4, 3, f);
+  int B = hdr[0], m = hdr[1], d = hdr[2];
+  std::vector<float> ctrs((size_t)B * m * d), pred((size_t)B * d);
+  fread(ctrs.data(), 4, ctrs.size(), f); fread(pred.data(), 4, pred.size(), f); fclose(f);
+  float *dc, *dp; unsigned long long* dout;
+  hipMalloc(&dc, ctrs.size() * 4); hipMalloc(&dp, pred.size() * 4); hipMalloc(&dout, (size_t)B * NSLOT * 8);
+  hipMemcpy(dc, ctrs.data(), ctrs.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dp, pred.data(), pred.size() * 4, hipMemcpyHostToDevice);
+  uint32_t lds = 64 * 1024, cap = 2600;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3(B), dim3(64), lds, 0, dc, dp, m, d, cap, lds, dout, 20);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> o((size_t)B * NSLOT);
+  hipMemcpy(o.data(), dout, o.size() * 8, hipMemcpyDeviceToHost);
+  const char* names[] = {"lite_build", "lite_gradient", "lite_gather (residual)", "refresh_clipped", "gj_solve (LOWER)",
+                         "general gradient (CSR, 4 lanes/row)", "general gather_mt (CSC)", "reduce_sum + reduce_max", "p", "chn", "cmax", "nnz"};
+  for (int s = 0; s < NSLOT; ++s) {
+    double sum = 0, mx = 0; for (int b = 0; b < B; ++b) { sum += o[(size_t)b * NSLOT + s]; mx = mx > o[(size_t)b * NSLOT + s] ? mx : o[(size_t)b * NSLOT + s]; }
+    printf("%-40s mean %9.1f  max %9.0f\n", names[s], sum / B, mx);
+  }
+  return 0;
+}
