@@ -256,6 +256,7 @@ int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t 
   memset(&P, 0, sizeof(P));
   P.ctrs = ctrs; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d;
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
+  if ((store->n_rows == nullptr) != (store->n_nnz == nullptr)) return fail(CAVE_E_INVALID, "pack_fill: n_rows and n_nnz go together");
   P.status = status; P.store = *store; P.slot0 = slot0; P.fill = 1;
   CAVE_LAUNCH(cone_pack_kernel, waves, B, lds_bytes, stream, P, "cone_pack_kernel(fill)");
   return CAVE_OK;

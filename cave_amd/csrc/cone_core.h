@@ -18,6 +18,11 @@
 //   quadratic model, exact line search on the true f).  proj = y - res*, rnorm = ||res*||_2.
 #pragma once
 #include <type_traits>
+#if defined(CAVE_STAMPS_FINE)
+#define CAVE_ACCF(slot) CAVE_ACC(slot)
+#else
+#define CAVE_ACCF(slot) do {} while (0)
+#endif
 #include "cone_common.h"
 #if defined(__HIPCC__)
 #include "wave_prims.h"
@@ -594,6 +599,60 @@ __device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, co
   if (lane < p) g[lane] = L.pfx[L.pend[lane + 1]] - L.pfx[L.pend[lane]];
   c.sync();
 }
+// H += (w_k - w_k_old) m_k m_k^T for the coordinates whose smoothed weight changed (see solve_cone_impl), lite
+// form: four coordinates per lane, all of their operands loaded before the first weight is computed; each
+// column comes in one 16-byte read and all lanes walk its (e1, e2 <= e1) pairs together, stopping at the longest
+// column that changed (no loads inside, so branching costs nothing there).  Only the LOWER triangle of H is
+// kept (columns are sorted by reduced row: e2 < e1 means b < a); gj_solve<.., LOWER> reads the rest transposed.
+template <class C>
+__device__ __forceinline__ void lite_hessian(C& c, const LiteCone& L, const SolveView& v, SolveWork& w, const double* r,
+                                             double mu, double inv_mu) {
+  constexpr int KC = kLiteMaxD / 64;
+  const int lane = c.lane_id(), d = v.d, ldh = w.ldh;
+  double rk[KC];
+  float wo[KC];
+  uint32_t us[KC];
+#pragma unroll
+  for (int s = 0; s < KC; ++s) {
+    const int k = lane + 64 * s, kc = k < d ? k : d - 1;
+    rk[s] = r[kc];
+    wo[s] = w.wold[kc];
+    us[s] = v.usign[kc];
+  }
+  const float imu = (float)inv_mu;
+#pragma unroll
+  for (int s = 0; s < KC; ++s) {
+    const int k = lane + 64 * s;
+    const uint32_t u = us[s];
+    const float t = (u == 2u) ? (float)rk[s] : -(float)rk[s];  // > 0 on the side that carries residual
+    const float z = t * imu;  // the weight is a heuristic, quantised anyway: float is plenty
+    float wn = t > 0.0f ? 1.0f : 0.0f;
+    if (mu > 0.0 && fabsf(z) < 4.0f) wn = floorf(8.0f * (1.0f + z * __builtin_amdgcn_rsqf(1.0f + z * z)) + 0.5f) * (1.0f / 16.0f);
+    wn = (u == 0u) ? 1.0f : (u == 3u) ? 0.0f : wn;
+    const bool changed = k < d && wn != wo[s];
+    if (__ballot(changed) == 0ull) continue;  // wave-uniform
+    if (changed) w.wold[k] = wn;
+    const double dw = (double)wn - (double)wo[s];
+    const uint4 t4 = *reinterpret_cast<const uint4*>(L.ell + 4 * (k < d ? k : d - 1));
+    const uint32_t cw[4] = {t4.x, t4.y, t4.z, t4.w};
+    static_for<0, 8>([&](auto e1c) {
+      constexpr int e1 = decltype(e1c)::value;
+      const uint32_t x1 = (cw[e1 >> 1] >> ((e1 & 1) * 16)) & 0xffffu;
+      const bool on1 = changed && (x1 & 0x7fffu) != kLiteDummyRow;
+      if (e1 < L.cmax && __ballot(on1) != 0ull) {
+        const uint32_t a = x1 & 0x7fffu;
+        const double va = (x1 & 0x8000u) ? -dw : dw;
+        double* Ha = w.H + a * ldh;
+        if (on1) c.atomic_add_f64(Ha + a, dw);
+        static_for<0, e1>([&](auto e2c) {
+          constexpr int e2 = decltype(e2c)::value;
+          const uint32_t x2 = (cw[e2 >> 1] >> ((e2 & 1) * 16)) & 0xffffu;
+          if (on1) c.atomic_add_f64(Ha + (x2 & 0x7fffu), (x2 & 0x8000u) ? -va : va);
+        });
+      }
+    });
+  }
+}
 #endif  // __HIPCC__
 
 // phi'(alpha) and phi''(alpha) of phi(alpha) = 1/2 || Pi(r - alpha q) ||^2
@@ -722,6 +781,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   for (; p > 0 && it < max_iter; ++it, cap07 *= 0.7, sched01 *= 0.1) {
     // gradient g = -M Pi(r) and projected-gradient norm
     gradient_any<C, PM1>(c, v, rc, w.g);
+    CAVE_ACCF(16);
     // Zig-zag extrapolation.  On degenerate cones (duplicated generators, y inside the cone) the iteration can
     // settle into a two-cycle of active sets and crawl along a valley at a linear rate.  From iteration 10 on,
     // every second iteration first minimises f exactly along theta - theta(two iterations ago), the valley
@@ -755,6 +815,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       for (int i = c.tid(); i < p; i += NT) w.told[i] = theta[i];
       c.sync();
     }
+    CAVE_ACCF(17);
     double pgmax = 0.0;
     for (int i = c.tid(); i < p; i += NT) {
       double gi = w.g[i];
@@ -873,6 +934,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // instance that converges normally)
       const double mu = 0.1 * ymax * fmin(pgn / g0n, cap07);
       const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
+      bool done = false;
+#if defined(__HIPCC__)
+      if constexpr (ctx_lite<C>::value) { lite_hessian(c, c.lite, v, w, r, mu, inv_mu); done = true; }
+#endif
+      if (!done)
       for (int k = c.tid(); k < d; k += NT) {
         const uint8_t u = v.usign[k];
         float wn;
@@ -885,35 +951,6 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           else wn = t > 0.0 ? 1.0f : 0.0f;
         }
         const float wo = w.wold[k];
-#if defined(__HIPCC__)
-        if constexpr (ctx_lite<C>::value) {
-          // lite form: the column comes in one 16-byte read; all lanes walk the (e1, e2 <= e1) pairs together and
-          // stop at the longest column that changed.  Only the LOWER triangle of H is kept (columns are sorted
-          // by reduced row, so e2 < e1 means b < a); gj_solve<.., LOWER> reads the rest transposed.
-          const bool changed = wn != wo;
-          if (__ballot(changed) == 0ull) continue;
-          if (changed) w.wold[k] = wn;
-          const double dw = (double)wn - (double)wo;
-          const uint4 t4 = *reinterpret_cast<const uint4*>(c.lite.ell + 4 * k);
-          const uint32_t cw[4] = {t4.x, t4.y, t4.z, t4.w};
-          static_for<0, 8>([&](auto e1c) {
-            constexpr int e1 = decltype(e1c)::value;
-            const uint32_t x1 = (cw[e1 >> 1] >> ((e1 & 1) * 16)) & 0xffffu;
-            const bool on1 = changed && (x1 & 0x7fffu) != kLiteDummyRow;
-            if (e1 < c.lite.cmax && __ballot(on1) != 0ull) {  // no loads inside: branching costs nothing here
-              const uint32_t a = x1 & 0x7fffu;
-              const double va = (x1 & 0x8000u) ? -dw : dw;
-              if (on1) c.atomic_add_f64(&w.H[a * ldh + a], dw);
-              static_for<0, e1>([&](auto e2c) {
-                constexpr int e2 = decltype(e2c)::value;
-                const uint32_t x2 = (cw[e2 >> 1] >> ((e2 & 1) * 16)) & 0xffffu;
-                if (on1) c.atomic_add_f64(&w.H[a * ldh + (x2 & 0x7fffu)], (x2 & 0x8000u) ? -va : va);
-              });
-            }
-          });
-          continue;
-        }
-#endif
         if (wn == wo) continue;
         w.wold[k] = wn;
         const double dw = (double)wn - (double)wo;
@@ -956,6 +993,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         w.dv[i] = w.g[i];  // dv doubles as the model gradient at tc
       }
       c.sync();
+      CAVE_ACCF(18);
       for (int inner = 0; inner <= p; ++inner) {
         // rhs: -model gradient on free rows, "go to zero" on fixed rows
         double* rhs = w.g2;
@@ -980,6 +1018,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           }
         }
         amin = -c.reduce_max(-amin);
+        CAVE_ACCF(19);
         const bool blocked = amin < 1.0;
         const double a = blocked ? fmax(amin, 0.0) : 1.0;
         // model gradient update  gm += a * H step  (only needed if another inner round follows)
@@ -1013,6 +1052,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           if (blocked) w.dv[i] += a * rhs[i];
         }
         c.sync();
+        CAVE_ACCF(20);
         if (!blocked) break;
       }
       double mv = 0.0;
@@ -1033,6 +1073,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     amax = -c.reduce_max(-amax);  // >= 1 because tc is feasible
     if (amax < 1.0) amax = 1.0;
     c.sync();
+    CAVE_ACCF(21);
     if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n); break; }
     // q = M^T dv, so r(alpha) = r - alpha q.  When the cost dimension fits KREG coordinates per
     // thread, q and r stay in registers for the whole search and the residual update is fused in.

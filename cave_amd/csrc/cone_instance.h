@@ -329,8 +329,10 @@ CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, i
   if (st == ST_OK && ar.ovf) st = ST_TOO_LARGE;
   if (st == ST_OK) {
     const int64_t r0 = S.row_off[slot], z0 = S.nnz_off[slot];
-    // the store was sized from pass 1; refuse to write past it
-    if ((int64_t)cb.p != S.row_off[slot + 1] - r0 || (int64_t)cb.nnzM != S.nnz_off[slot + 1] - z0) st = ST_BAD_INPUT;
+    const bool slots = S.n_rows != nullptr;  // slot mode: the offsets are capacity windows
+    // exact-fit store: it was sized from pass 1, refuse to write past it; slot mode: the instance must fit its window
+    if (!slots && ((int64_t)cb.p != S.row_off[slot + 1] - r0 || (int64_t)cb.nnzM != S.nnz_off[slot + 1] - z0)) st = ST_BAD_INPUT;
+    else if (slots && ((int64_t)cb.p > S.row_off[slot + 1] - r0 || (int64_t)cb.nnzM > S.nnz_off[slot + 1] - z0)) st = ST_TOO_LARGE;
     else {
       compute_avg(c, cb, avg);
       for (int k = c.tid(); k < d; k += NT) {
@@ -360,6 +362,10 @@ CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, i
       }
     }
   }
+  if (S.n_rows != nullptr && c.tid() == 0) {
+    S.n_rows[slot] = st == ST_OK ? cb.p : -1;  // -1: this slot holds no cone (the packed operator reports TOO_LARGE)
+    S.n_nnz[slot] = st == ST_OK ? (int32_t)cb.nnzM : 0;
+  }
   if (c.tid() == 0 && P.status) P.status[b] = st;
 }
 
@@ -374,10 +380,11 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
   int32_t st = ST_OK;
   int iters = 0;
   if (slot < 0 || slot >= S.n) st = ST_BAD_INPUT;
+  else if (S.n_rows && S.n_rows[slot] < 0) st = ST_TOO_LARGE;  // slot mode: the cone did not fit its slot when packed
   else {
     const int64_t r0 = S.row_off[slot], z0 = S.nnz_off[slot];
-    const int p = (int)(S.row_off[slot + 1] - r0);
-    const uint32_t nz = (uint32_t)(S.nnz_off[slot + 1] - z0);
+    const int p = S.n_rows ? (int)S.n_rows[slot] : (int)(S.row_off[slot + 1] - r0);
+    const uint32_t nz = S.n_nnz ? (uint32_t)S.n_nnz[slot] : (uint32_t)(S.nnz_off[slot + 1] - z0);
     const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
     const bool need_proj = (P.mode == MODE_PROJECT || P.mode == MODE_EXACT || P.mode == MODE_INNER);
     float* y = ar.get<float>(d);
@@ -448,10 +455,11 @@ CAVE_HD void run_packed_large_instance(C& c, unsigned char* smem, const PackedPa
   int32_t st = ST_OK;
   int iters = 0;
   if (slot < 0 || slot >= S.n) st = ST_BAD_INPUT;
+  else if (S.n_rows && S.n_rows[slot] < 0) st = ST_TOO_LARGE;  // slot mode: the cone did not fit its slot when packed
   else {
     const int64_t r0 = S.row_off[slot], z0 = S.nnz_off[slot];
-    const int p = (int)(S.row_off[slot + 1] - r0);
-    const uint32_t nz = (uint32_t)(S.nnz_off[slot + 1] - z0);
+    const int p = S.n_rows ? (int)S.n_rows[slot] : (int)(S.row_off[slot + 1] - r0);
+    const uint32_t nz = S.n_nnz ? (uint32_t)S.n_nnz[slot] : (uint32_t)(S.nnz_off[slot + 1] - z0);
     const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
     float* y = ar.get<float>(d);
     uint32_t* mptr = ar.get<uint32_t>((uint32_t)p + 1u);

@@ -17,7 +17,7 @@ struct WaveCtx {
   static constexpr int KREG = 4;         // line search keeps r, q in registers when d <= KREG * NT
   static constexpr uint32_t SCRATCH_BYTES = 0;
   static constexpr int NWAVES = 1;       // waves per instance
-  static constexpr int MIN_WAVES_PER_EU = 1;
+  static constexpr int MIN_WAVES_PER_EU = 2;  // 256 registers: two one-wave workgroups per SIMD (B > 1024 keeps latency hiding)
   static constexpr int WL = 64;          // lanes per wave
   int lane;
 #ifdef CAVE_STAMPS

@@ -187,6 +187,9 @@ class ConeStore:
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
         self.waves = 0  # 0 = choose per call
         self.all_pm1 = bool((t["flags"] & 1).all()) if N else False
+        # every instance qualifies for the one-wave lite solver (cone_core.h: +-1 entries, <= 32 reduced rows,
+        # <= 1024 non-zeros, d <= 256; columns with more than 8 entries fall back inside the kernel)
+        self.lite = self.all_pm1 and self.max_rows <= 32 and self.max_nnz <= 1024 and d <= 256
         self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, int(self.all_pm1)))
         # cones beyond the LDS-resident solver (more than 64 reduced rows or too many non-zeros) run on the
         # large-cone path, which reads the store in place and keeps the Newton systems as bands
@@ -222,6 +225,8 @@ class ConeStore:
         puts more instances in flight and wins on throughput (measured crossover between 1024 and 2048)."""
         if self.waves in (1, 2, 4, 8):
             return self.waves if (self.waves != 4 or self.fits4) else 2
+        if self.lite:
+            return 1  # small +-1 cones: the one-wave kernels carry the lite solver (cone_core.h)
         if self.lds_bytes > 80 * 1024:
             return 8  # one workgroup per CU whatever the shape: four waves with the wide register budget (64 rows)
         if self.fits4 and B <= 1280:

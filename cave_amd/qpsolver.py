@@ -76,6 +76,7 @@ def forget_shape(m: int, d: int) -> None:
     _tier.pop(key, None)
     _wide_ok.pop(key, None)
     _large_hint.pop(key, None)
+    _split_ok.pop(key, None)
     _settled.discard(key)
 
 
@@ -91,6 +92,59 @@ def fast_path_cannot_fit(d: int) -> bool:
     """The per-coordinate arrays of the LDS-resident solver (sign byte, column pointers, y, avg,
     residual, clipped residual, direction, flags: ~38 bytes per cost coordinate) alone exceed 160 KiB."""
     return 38 * d + 4096 > _lib.MAX_LDS
+
+
+# ---- "split" form of the dense operator for small cones (d <= 256):
+#   kernel 1  cave_hip_pack_fill in slot mode: four waves per instance stream the dense block and leave the
+#             reduced cone in a fixed-capacity slot of a transient device store (one pass over the dense bytes);
+#   kernel 2  cave_hip_cone_packed with ONE wave per instance, whose small-cone ("lite") solver wants ~200
+#             registers -- more than the 4-wave streaming shape can give without losing residency.
+# The two kernels each get the launch shape they need; the transient store costs ~10 KB of extra HBM traffic per
+# instance against 178 KB of dense input (TSP-20).  Instances beyond the slot capacity (more than 32 reduced
+# rows / 1024 non-zeros, or entries other than +-1) report TOO_LARGE and the batch falls back to the fused kernel.
+SPLIT_MAX_D, SPLIT_ROWS, SPLIT_NNZ = 256, 32, 1024
+_slot_stores: dict = {}
+_split_ok: dict[tuple[int, int], bool] = {}  # (m, d) -> the split form fitted every instance of a checked batch
+
+
+class _SlotStore:
+    def __init__(self, dev, B: int, d: int):
+        import ctypes as C
+
+        self.B, self.d = B, d
+        t = {}
+        ar = torch.arange(B + 1, dtype=torch.int64, device=dev)
+        t["row_off"], t["nnz_off"] = ar * SPLIT_ROWS, ar * SPLIT_NNZ
+        R, Z = B * SPLIT_ROWS, B * SPLIT_NNZ
+        t["n_valid"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        t["flags"] = torch.zeros(B, dtype=torch.uint8, device=dev)
+        t["usign"] = torch.zeros(B * d, dtype=torch.uint8, device=dev)
+        t["avg"] = torch.zeros(B * d, dtype=torch.float32, device=dev)
+        t["vkind"] = torch.zeros(R, dtype=torch.uint8, device=dev)
+        t["rlo"] = torch.zeros(R, dtype=torch.int32, device=dev)
+        t["rhi"] = torch.zeros(R, dtype=torch.int32, device=dev)
+        t["ccol"] = torch.zeros(Z, dtype=torch.int16, device=dev)
+        t["cval"] = torch.zeros(Z, dtype=torch.float32, device=dev)
+        t["cptr"] = torch.zeros(B * (d + 1), dtype=torch.int32, device=dev)
+        t["cvar"] = torch.zeros(Z, dtype=torch.int16, device=dev)
+        t["cvalc"] = torch.zeros(Z, dtype=torch.float32, device=dev)
+        t["n_rows"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        t["n_nnz"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.t = t
+        self.c = _lib.Store(n=B, d=d, reserved=0, **{k: v.data_ptr() for k, v in t.items()})
+        self.ref = C.byref(self.c)
+        self.pack_status = torch.empty(B, dtype=torch.int32, device=dev)
+        self.lds_bytes = int(_lib.load_library().cave_hip_packed_lds_bytes(d, SPLIT_ROWS, SPLIT_NNZ, 1))
+
+
+def _slot_store(dev, B: int, d: int) -> _SlotStore:
+    key = (dev, B, d)
+    st = _slot_stores.get(key)
+    if st is None:
+        if len(_slot_stores) >= 4:
+            _slot_stores.pop(next(iter(_slot_stores)))
+        st = _slot_stores[key] = _SlotStore(dev, B, d)
+    return st
 
 
 def _raise_for_status(status: torch.Tensor, what: str) -> None:
@@ -189,6 +243,34 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             _large_hint[(m, d)] = (cap, band)
 
         auto = lds_bytes == 0
+
+        def launch_split() -> None:
+            ss = _slot_store(dev, B, d)
+            if ss.lds_bytes <= 0:
+                raise HipSolverError("split form: no LDS configuration")
+            rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, int(nnz_cap), 0, 4, ss.ref, 0, _lib.ptr(ss.pack_status),
+                                        _lib.current_stream())
+            _lib.check(rc, "cave_hip_pack_fill (slot mode)")
+            rc = lib.cave_hip_cone_packed(
+                ss.ref, None, _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio), int(max_iter), ss.lds_bytes, 1,
+                _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
+                _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+                _lib.current_stream())
+            _lib.check(rc, "cave_hip_cone_packed (slot mode)")
+
+        # small cones: the split form, once a checked batch of this shape has fitted it (or when this call is checked)
+        if auto and waves == 0 and 0 < m and d <= SPLIT_MAX_D and (m, d) not in _tier:
+            ok = _split_ok.get((m, d))
+            if ok is True or (ok is None and check):
+                launch_split()
+                if not check:
+                    return out
+                fits = not bool((status == ST_TOO_LARGE).any())
+                _split_ok[(m, d)] = fits
+                if fits:
+                    _raise_for_status(status, "solver='hip'")
+                    _settled.add((m, d))
+                    return out
         if auto and (m, d) not in _tier and fast_path_cannot_fit(d):
             _tier[(m, d)] = 2
         tier = _tier.get((m, d), 0) if auto else 0

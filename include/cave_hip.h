@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 5
+#define CAVE_HIP_ABI_VERSION 6
 
 /* return codes */
 #define CAVE_OK 0
@@ -137,6 +137,13 @@ typedef struct cave_cone_store {
   uint32_t* cptr;
   uint16_t* cvar;
   float* cvalc;
+  /* Slot mode (both NULL in an exact-fit store).  When set, row_off / nnz_off only give each slot its
+   * CAPACITY window (e.g. slot * max_rows, slot * max_nnz) and the actual sizes are n_rows[slot] / n_nnz[slot]:
+   * cave_hip_pack_fill then needs no count pass (an instance that does not fit its window reports
+   * CAVE_ST_TOO_LARGE and sets n_rows[slot] = -1, which cave_hip_cone_packed reports as CAVE_ST_TOO_LARGE too), which is how the dense operator runs small cones as
+   * "pack into a transient slot store, then cave_hip_cone_packed" in one pass over the dense bytes. */
+  int32_t* n_rows;
+  int32_t* n_nnz;
 } cave_cone_store;
 
 /* Pass 2: fill the store for instances [0, B) of `ctrs` at store slots [slot0, slot0+B). */

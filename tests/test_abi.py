@@ -20,7 +20,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cave_hip_version() == 5
+    assert lib.cave_hip_version() == 6
     assert lib.cave_hip_device_count() >= 0
     assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
 
@@ -29,7 +29,7 @@ def test_default_limits_and_arg_validation():
     cap, lds = _lib.default_limits(235, 190)  # TSP-20
     assert 1500 <= cap <= 235 * 190 and 0 < lds <= 40 * 1024  # >= 4 workgroups per CU
     cap, lds = _lib.default_limits(15, 10)
-    assert cap == 150 and lds <= 16 * 1024
+    assert cap == 150 and lds <= 20 * 1024
     lib = _lib.load_library()
     # bad shapes are rejected before any launch (works without a GPU)
     assert lib.cave_hip_cone_dense(None, None, 1, 4, 0, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
@@ -37,7 +37,9 @@ def test_default_limits_and_arg_validation():
     assert lib.cave_hip_cone_dense(None, None, 1, 4, 70000, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.cave_hip_cone_dense(None, None, 1, 4, 4, 9, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.cave_hip_cone_dense(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 0, 0, 0, None, None, None, None, None, None, None, None) == 0  # B == 0
-    assert 0 < lib.cave_hip_packed_lds_bytes(190, 26, 700, 1) < lib.cave_hip_packed_lds_bytes(190, 26, 700, 0)
+    # +-1 cones keep no value arrays; small ones (d <= 256, <= 32 rows) add the index structures of the one-wave solver
+    assert 0 < lib.cave_hip_packed_lds_bytes(1225, 55, 3000, 1) < lib.cave_hip_packed_lds_bytes(1225, 55, 3000, 0)
+    assert 0 < lib.cave_hip_packed_lds_bytes(190, 26, 700, 0) < lib.cave_hip_packed_lds_bytes(190, 26, 700, 1) <= 40 * 1024
     assert lib.cave_hip_packed_lds_bytes(190, 5000, 700, 0) == -1
     # large-cone entry points: sizing is monotone, bad workspaces / shapes are rejected before any launch
     s1 = lib.cave_hip_large_slice_bytes(5155, 4950, 40000, 16000)

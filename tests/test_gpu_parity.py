@@ -67,8 +67,8 @@ def test_auto_launch_shape_falls_back(hip):
         A[:, :, 0] = 1.0                                                                              # no empty / unit rows
         A[:, :, 1] = rng.standard_normal((8, m))
         y = rng.standard_normal((8, 30)).astype(np.float32)
-        qpsolver._wide_ok.pop((m, 30), None)
-        qpsolver._tier.pop((m, 30), None)
+        qpsolver.forget_shape(m, 30)
+        qpsolver._split_ok[(m, 30)] = False  # this test is about the tiers of the FUSED kernel
         o = hip(A, y, MODE_PROJECT, 1.0, 0.0)
         assert (o["status"] == 0).all()
         assert qpsolver._wide_ok[(m, 30)] is fits

@@ -177,6 +177,7 @@ def test_lazy_check_with_mixed_cone_sizes_under_one_shape():
     small, big = cones(20), cones(44)
     y = rng.standard_normal((B, d)).astype(np.float32)
     qpsolver.forget_shape(m, d)
+    qpsolver._split_ok[(m, d)] = False  # the fused kernel's shape cache is what is under test here
     mod = exactConeAlignedCosine(_M(), solver="hip", solver_kwargs={"check": "lazy"}, reduction="none")
     p = torch.tensor(y, device="cuda", requires_grad=True)
     l0 = mod(p, torch.tensor(small, device="cuda"))          # first call for the shape: strict, settles on 4 waves
@@ -189,8 +190,50 @@ def test_lazy_check_with_mixed_cone_sizes_under_one_shape():
     with pytest.raises(HipSolverError):
         mod(p, torch.tensor(small, device="cuda"))           # the verdict arrives here ...
     assert (m, d) not in qpsolver._settled and (m, d) not in qpsolver._wide_ok  # ... and the shape is forgotten
+    qpsolver._split_ok[(m, d)] = False
     flush_checks()
     l2 = mod(p, torch.tensor(big, device="cuda"))            # strict again: falls back to a shape that fits
     want = O.cone_loss(y, O.exact_target(y, big)[0], 1.0)
     assert np.abs(l2.detach().cpu().numpy() - want).max() <= 2e-6
     flush_checks()
+
+
+def test_split_form_of_the_dense_operator(golden):
+    """Small cones: cone_op_dense runs 'pack into transient slots + one-wave packed solve' (qpsolver.launch_split).
+    Same results as the reference fixtures, bit-identical to the packed store, and a batch with an instance
+    beyond the slot capacity falls back to the fused kernel."""
+    import torch
+
+    from cave_amd import qpsolver, synth
+    from cave_amd.dataset import ConeStore
+    from cave_amd.qpsolver import cone_op_dense
+
+    for file, tag in CASES:
+        g = golden[file]
+        qpsolver.forget_shape(*g[f"{tag}_ctrs"].shape[1:])
+        check_case(_dense_impl(), golden, file, tag)
+    ctrs, costs, _ = synth.tsp_batch(20, 200, seed=9)
+    key = (ctrs.shape[1], ctrs.shape[2])
+    qpsolver.forget_shape(*key)
+    c, p = torch.tensor(ctrs, device="cuda"), torch.tensor(costs, device="cuda")
+    a = cone_op_dense(c, p, MODE_INNER, -1.0, 0.2, outputs=ALL)
+    assert qpsolver._split_ok.get(key) is True
+    store = ConeStore.from_dense(c)
+    b = store.cone_op(torch.arange(200, device="cuda"), p, MODE_INNER, -1.0, 0.2, outputs=ALL)
+    for k in ALL:
+        assert torch.equal(a[k], b[k]), k
+    a2 = cone_op_dense(c, p, MODE_INNER, -1.0, 0.2, outputs=ALL, check=False)  # unchecked: uses what was learnt
+    for k in ALL:
+        assert torch.equal(a[k], a2[k]), k
+    # one dense row block turns an instance into a non +-1 cone with 40 general rows: beyond the slots
+    rng = np.random.default_rng(0)
+    big = ctrs[:8].copy()
+    big[3, :40, :30] = rng.standard_normal((40, 30)).astype(np.float32)
+    qpsolver.forget_shape(*key)
+    o = cone_op_dense(torch.tensor(big, device="cuda"), p[:8], MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    assert qpsolver._split_ok.get(key) is False and bool((o["status"] == 0).all())
+    from oracle import cave_oracle as O
+
+    po, ro = O.batch_project(-costs[:8], big)
+    assert np.abs(o["proj"].cpu().numpy() - po).max() <= 4e-6 * np.abs(costs[:8]).max()
+    qpsolver.forget_shape(*key)
