@@ -149,6 +149,7 @@ struct SolveWork {
   double* H;       // [p*ldh]  dense rows, or (band form) H[j*ldh + t] = H(j+t, j), t = 0..bw, ldh = bw+1
   uint8_t* act;    // [p]
   float* wold;     // [d]  weight each coordinate currently has in H (fast path; the band path rebuilds H)
+  const float* warm;  // [p] multipliers of an earlier solve of this cone (global memory), or null: starting point
   int ldh;
   // band form only (large-cone path, cone_band.h)
   bool band_hot;   // bwin, bz, step and act all live in LDS (typed fast variant of the band solver)

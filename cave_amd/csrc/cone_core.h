@@ -757,7 +757,15 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   double* tc = w.ttry;  // working point of the inner loop
   double* r = w.res;    // UNCLIPPED residual y - M^T theta during the iteration
   double* rc = w.rc;    // its clipped image Pi(r)
-  for (int i = c.tid(); i < p; i += NT) theta[i] = 0.0;
+  // Starting point: theta = 0, or (warm start) the multipliers a previous solve of the SAME cone ended with --
+  // cones are static per instance and predictions drift slowly during training (src/dataset.py:72), so the old
+  // active set is nearly right.  The projection is unique, so the result does not depend on the start.
+  const bool warm = w.warm != nullptr;
+  for (int i = c.tid(); i < p; i += NT) {
+    double t0 = warm ? (double)w.warm[i] : 0.0;
+    if (!(t0 == t0) || fabs(t0) > 1e30 || (!v.vkind[i] && t0 < 0.0)) t0 = 0.0;
+    theta[i] = t0;
+  }
   double yy = 0.0, ymax = 0.0;
   for (int k = c.tid(); k < d; k += NT) {
     yy += (double)w.y[k] * (double)w.y[k];
@@ -768,13 +776,23 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   ymax = c.reduce_max(ymax);
   c.sync();
   double f = refresh_clipped(c, v, r, rc);
+  double g0n = 0.0;
+  if (warm && p > 0) {
+    // the convergence test is relative to the projected gradient AT theta = 0 (what a cold start measures in its
+    // first iteration), not at the warm point, where it is already small
+    gradient_any<C, PM1>(c, v, rc, w.g);
+    double gm = 0.0;
+    for (int i = c.tid(); i < p; i += NT) gm = fmax(gm, fabs(v.vkind[i] ? w.g[i] : fmin(w.g[i], 0.0)));
+    g0n = c.reduce_max(gm);
+    gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
+    f = refresh_clipped(c, v, r, rc);
+  }
   const int ldh = w.ldh;
   for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
   if constexpr (!BAND) for (int k = c.tid(); k < d; k += NT) w.wold[k] = 0.f;
   c.sync();
-  double g0n = 0.0;
   double reg_rel = 1e-12;  // Levenberg shift relative to max diag(H); raised when a step stalls
-  double cap07 = 1.0, sched01 = 1.0;  // 0.7^it and 0.1^it, kept as running products (pow() is ~300 instructions)
+  double cap07 = 1.0, sched01 = warm ? 0.0 : 1.0;  // 0.7^it and 0.1^it, kept as running products (pow() is ~300 instructions)
   bool converged = (p == 0);
   int it = 0;
   CAVE_T0();
@@ -823,7 +841,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       pgmax = fmax(pgmax, fabs(pg));
     }
     double pgn = c.reduce_max(pgmax);
-    if (it == 0) g0n = pgn;
+    if (it == 0 && !(warm && g0n > 0.0)) g0n = pgn;
 #ifdef CAVE_TRACE
     printf("it %d f %.10e pgn %.6e\n", it, f, pgn);
 #endif

@@ -133,10 +133,14 @@ CAVE_HD T* hot_get(Arena* hot, Arena& ar, uint32_t n) {
 
 // Solve + epilogue for one instance whose SolveView is ready.  y must be loaded.
 // LARGE: band Hessian + solve_spd_band, work arrays hot-first (`hot` = LDS arena, `ar` = global workspace).
+// warm_theta / warm_state: this instance's slice of the store's multiplier cache (global memory) and its
+// state byte, or null (no warm start): read as the starting point when the state is 1, rewritten after a
+// converged solve, invalidated after a failed one.
 template <class C, bool LARGE = false>
 CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v, int mode, float sign,
                                  float inner_ratio, int max_iter, float* y, const float* avg, int64_t b,
-                                 const OutPtrs& o, int* iters_out) {
+                                 const OutPtrs& o, int* iters_out, float* warm_theta = nullptr,
+                                 uint8_t* warm_state = nullptr) {
   const int d = v.d;
   const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER);
   int32_t st = ST_OK;
@@ -156,6 +160,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     SolveWork w;
     w.y = y;
     w.bw = 0; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
+    w.warm = (warm_theta && warm_state && *warm_state == 1) ? warm_theta : nullptr;
     if constexpr (LARGE) {
       const int bw = band_halfwidth(c, v);
       const uint32_t ld = (uint32_t)bw + 1u;
@@ -231,8 +236,10 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       // small +-1 cone on a one-wave workgroup: Newton iteration over the lite index structures (cone_core.h).
       // (Only the one-wave kernels carry this path: it wants ~200 VGPRs, and inlined into the 4-wave kernels,
       // whose residency rests on a 128-VGPR budget, it cost 650 bytes of scratch per lane.)
+      // (a latency design: beyond ~2 instances per SIMD the general path's lower instruction count wins --
+      //  packed TSP-20 at B = 4096: 374 us with the lite solver)
       LiteCone L;
-      lite = lite_build(c, ar, vv, L);
+      lite = gridDim.x <= 2048u && lite_build(c, ar, vv, L);
       if (lite) {
         SoloCtx<32, 4> sc;
         sc.lane = c.lane_id();
@@ -251,6 +258,10 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
+    if (warm_theta && warm_state) {  // keep the multipliers for the next solve of this cone
+      if (st == ST_OK) for (int i = c.tid(); i < p; i += C::NT) warm_theta[i] = (float)w.theta[i];
+      if (c.tid() == 0) *warm_state = (uint8_t)(st == ST_OK ? 1 : 0);
+    }
     if (st == ST_BAD_INPUT) return st;
   } else if constexpr (LARGE) {
     res = ar.get<double>(d);
@@ -430,7 +441,8 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
       v.mptr = mptr; v.mcol = mcol; v.mval = mval; v.vkind = vkind;
       v.cptr = cptr; v.cvar = cvar; v.cvalc = cvalc; v.usign = usign;
       v.nlong = 0; v.longrow = nullptr;
-      st = solve_and_finish(c, ar, nullptr, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+      st = solve_and_finish(c, ar, nullptr, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters,
+                            S.warm_theta ? S.warm_theta + r0 : nullptr, S.warm_state ? S.warm_state + slot : nullptr);
     }
   }
   if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);
@@ -475,7 +487,9 @@ CAVE_HD void run_packed_large_instance(C& c, unsigned char* smem, const PackedPa
       v.cptr = S.cptr + slot * (d + 1); v.cvar = S.cvar + z0; v.cvalc = S.cvalc + z0; v.usign = S.usign + slot * d;
       v.nlong = 0; v.longrow = nullptr;
       const float* avg = need_avg ? S.avg + slot * d : nullptr;
-      st = solve_and_finish<C, true>(c, ar, &hot, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters);
+      st = solve_and_finish<C, true>(c, ar, &hot, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters,
+                                     S.warm_theta ? S.warm_theta + r0 : nullptr,
+                                     S.warm_state ? S.warm_state + slot : nullptr);
     }
   }
   if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);

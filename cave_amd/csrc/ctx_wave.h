@@ -100,7 +100,7 @@ struct WaveCtx {
   }
   __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                             double reg_rel, double* dv) const {
-    gj_solve<64>(lane, H, ldh, g, act, p, reg_rel, dv);
+    gj_solve_small<64>(lane, H, ldh, g, act, p, reg_rel, dv);  // the low-register form: this kernel shape is built for two waves per SIMD
   }
 
   // Stream one dense instance (n floats, row-major) and append its non-zeros, in flat (row-major)

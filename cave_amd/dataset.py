@@ -184,6 +184,7 @@ class ConeStore:
                                                   _lib.ptr(status), stream), "cave_hip_pack_fill")
             _raise_for_status(status, "ConeStore fill")
             slot += B
+        self.warm_start = False
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
         self.waves = 0  # 0 = choose per call
         self.all_pm1 = bool((t["flags"] & 1).all()) if N else False
@@ -233,6 +234,26 @@ class ConeStore:
             return 4  # measured (TSP-20, packed): 116 vs 129 us at B = 256, 138 vs 145 us at B = 1024
         return 2 if B <= 1280 else 1
 
+    # ------------------------------------------------------------- warm start
+    def enable_warm_start(self, on: bool = True) -> None:
+        """Opt-in: keep, per instance, the multipliers its last converged projection ended with (4 bytes per
+        reduced row) and start the next projection of that instance there.  Cones are static per instance and
+        predictions drift slowly from one epoch to the next (src/dataset.py:72), so the old active set is nearly
+        right: TSP-20 training needs ~2 Newton iterations per step instead of ~5.  The projection is unique, so
+        results equal those of a cold start to the solver's tolerance.  A failed solve invalidates its entry."""
+        if on and "warm_theta" not in self.t:
+            R = int(self.t["row_off"][-1])
+            self.t["warm_theta"] = torch.zeros(max(R, 1), dtype=torch.float32, device=self.device)
+            self.t["warm_state"] = torch.zeros(max(self.n, 1), dtype=torch.uint8, device=self.device)
+        self.warm_start = bool(on)
+        self._c.warm_theta = self.t["warm_theta"].data_ptr() if on else None
+        self._c.warm_state = self.t["warm_state"].data_ptr() if on else None
+
+    def reset_warm_start(self) -> None:
+        """Forget every cached multiplier (the next projections start cold)."""
+        if "warm_state" in self.t:
+            self.t["warm_state"].zero_()
+
     def nbytes(self) -> int:
         return sum(v.numel() * v.element_size() for v in self.t.values())
 
@@ -281,6 +302,7 @@ class ConeStore:
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())
                 _lib.check(rc, "cave_hip_cone_packed")
+            self.last_iters = iters  # Newton iterations of the most recent call (device tensor; diagnostics)
             if check:
                 _raise_for_status(status, "solver='hip' (packed)")
         return out

@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""End-to-end CaVE training on the grid shortest path with `solver='hip'` — the loop of the
-reference's code_sample.py:23-60 (linear predictor, Adam lr 1e-2, CaVE+ loss), BASELINE configs[0]
-sizes by default (5x5 grid, 100 instances, batch 32), no Gurobi / PyEPO needed.
+"""End-to-end CaVE training with `solver='hip'` — the loop of the reference's code_sample.py:23-60 (linear
+predictor, Adam lr 1e-2, CaVE+ loss), no Gurobi / PyEPO needed.  Default: the grid shortest path at
+BASELINE configs[0] sizes (5x5 grid, 100 instances, batch 32); `--problem tsp` is code_sample.py's own problem
+(DFJ TSP) at a size the Held-Karp / HiGHS tight-cone builder of cave_amd/tight.py handles exactly.
 
     python examples/train_sp_cave.py [--grid 5 5] [--num-data 100] [--batch 32] [--epochs 10] [--packed]
+    python examples/train_sp_cave.py --problem tsp --nodes 10 --packed --warm-start
 """
 
 import argparse
@@ -28,16 +30,25 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--variant", default="inner", choices=["exact", "inner", "hybrid"])
     ap.add_argument("--packed", action="store_true", help="device-resident packed cones instead of dense padding")
+    ap.add_argument("--problem", default="sp", choices=["sp", "tsp"])
+    ap.add_argument("--nodes", type=int, default=10, help="TSP size (Held-Karp: <= 14)")
+    ap.add_argument("--warm-start", action="store_true",
+                    help="(with --packed) start each projection from the multipliers of the previous epoch")
     args = ap.parse_args(argv)
 
     from cave_amd.cave import EPO, exactConeAlignedCosine, innerConeAlignedCosine
     from cave_amd.dataset import ConeStore, PackedBatch
-    from cave_amd.tight import SPConeDataset, sp_gen_data, sp_regret
+    from cave_amd.tight import (SPConeDataset, TSPConeDataset, sp_gen_data, sp_regret, tsp_gen_data, tsp_regret)
     from torch.nn.utils.rnn import pad_sequence
 
     h, w = args.grid
-    feats, costs = sp_gen_data(args.num_data, args.num_feat, h, w, deg=4, noise_width=0.5, seed=135)
-    dataset = SPConeDataset(feats, costs, h, w)
+    if args.problem == "tsp":
+        feats, costs = tsp_gen_data(args.num_data, args.num_feat, args.nodes, deg=4, noise_width=0.5, seed=42)
+        dataset = TSPConeDataset(feats, costs, args.nodes)
+        print(f"TSP-{args.nodes}: {len(dataset)} instances, {sum(dataset.tight_cuts)} tight subtour cuts in all")
+    else:
+        feats, costs = sp_gen_data(args.num_data, args.num_feat, h, w, deg=4, noise_width=0.5, seed=135)
+        dataset = SPConeDataset(feats, costs, h, w)
     dev = torch.device("cuda")
 
     class _Model:  # what the loss modules read from a PyEPO optModel
@@ -51,6 +62,8 @@ def main(argv=None):
         cave = innerConeAlignedCosine(_Model(), solver="hip", solve_ratio=0.3, inner_ratio=0.2, seed=0)
 
     store = ConeStore.from_ragged(dataset.ctrs) if args.packed else None
+    if store is not None and args.warm_start:
+        store.enable_warm_start()
 
     def collate(batch):  # reference collate_fn (src/dataset.py:133-144) / its id-returning replacement
         idx = torch.as_tensor(batch, dtype=torch.int64)
@@ -69,13 +82,17 @@ def main(argv=None):
     def regret():
         with torch.no_grad():
             cp = reg(dataset.feats.to(dev)).cpu().numpy()
+        if args.problem == "tsp":
+            return tsp_regret(cp, dataset.costs.numpy(), dataset.objs.numpy()[:, 0], args.nodes)
         return sp_regret(cp, dataset.costs.numpy(), dataset.objs.numpy()[:, 0], h, w)
 
     hist = [(0, float("nan"), regret())]
     print(f"epoch 0: regret {hist[0][2] * 100:.2f}%")
     t0 = time.time()
+    iters_log = []
     for epoch in range(1, args.epochs + 1):
         tot = 0.0
+        it_sum, it_max, it_n = 0.0, 0, 0
         for x, c, cones in loader:
             x = x.to(dev)
             cp = reg(x)
@@ -84,8 +101,16 @@ def main(argv=None):
             loss.backward()
             opt.step()
             tot += float(loss.detach()) * len(x)
+            if store is not None and getattr(store, "last_iters", None) is not None:
+                li = store.last_iters
+                it_sum, it_max, it_n = it_sum + float(li.sum()), max(it_max, int(li.max())), it_n + li.numel()
         hist.append((epoch, tot / len(dataset), regret()))
-        print(f"epoch {epoch}: loss {hist[-1][1]:.4f}  regret {hist[-1][2] * 100:.2f}%")
+        extra = ""
+        if it_n:
+            iters_log.append((it_sum / it_n, it_max))
+            extra = f"  Newton iterations mean {it_sum / it_n:.2f} max {it_max}"
+        print(f"epoch {epoch}: loss {hist[-1][1]:.4f}  regret {hist[-1][2] * 100:.2f}%{extra}")
+    main.iters_log = iters_log
     print(f"training time {time.time() - t0:.2f} s ({args.epochs} epochs, {len(dataset)} instances, batch {args.batch})")
     return hist
 

@@ -144,6 +144,13 @@ typedef struct cave_cone_store {
    * "pack into a transient slot store, then cave_hip_cone_packed" in one pass over the dense bytes. */
   int32_t* n_rows;
   int32_t* n_nnz;
+  /* Warm start (both NULL: off).  warm_theta [R] float32, aligned with the reduced rows, holds the multipliers the
+   * last converged projection of each instance ended with; warm_state [n] is 1 where that is valid (the caller
+   * zeroes it to reset).  cave_hip_cone_packed(_large) then starts the Newton iteration there and refreshes both.
+   * Cones are static per instance and predictions drift slowly during training (src/dataset.py:72); the
+   * projection is unique, so results are the same as from a cold start (to the solver's tolerance). */
+  float* warm_theta;
+  uint8_t* warm_state;
 } cave_cone_store;
 
 /* Pass 2: fill the store for instances [0, B) of `ctrs` at store slots [slot0, slot0+B). */

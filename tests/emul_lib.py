@@ -46,6 +46,7 @@ class Store(C.Structure):
         ("rlo", C.c_void_p), ("rhi", C.c_void_p), ("ccol", C.c_void_p), ("cval", C.c_void_p),
         ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),
         ("n_rows", C.c_void_p), ("n_nnz", C.c_void_p),  # slot mode only (NULL in an exact-fit store)
+        ("warm_theta", C.c_void_p), ("warm_state", C.c_void_p),  # warm start (NULL: off)
     ]
 
 

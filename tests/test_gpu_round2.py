@@ -237,3 +237,63 @@ def test_split_form_of_the_dense_operator(golden):
     po, ro = O.batch_project(-costs[:8], big)
     assert np.abs(o["proj"].cpu().numpy() - po).max() <= 4e-6 * np.abs(costs[:8]).max()
     qpsolver.forget_shape(*key)
+
+
+def test_warm_start_matches_cold_start_and_saves_iterations(golden):
+    """ConeStore.enable_warm_start(): projections started from the multipliers of the previous solve of the
+    same instance equal cold-start projections (the projection is unique) and need fewer Newton iterations
+    once the prediction has only drifted."""
+    import torch
+
+    from cave_amd.dataset import ConeStore
+
+    g = golden["structured"]
+    ctrs, costs = g["tsp20_ctrs"], g["tsp20_costs"]
+    B = len(ctrs)
+    c = torch.tensor(ctrs, device="cuda")
+    cold, warm = ConeStore.from_dense(c), ConeStore.from_dense(c)
+    warm.enable_warm_start()
+    ids = torch.arange(B, device="cuda")
+    rng = np.random.default_rng(4)
+    sc = float(np.abs(costs).max())
+    for waves in (0, 4):
+        pred = torch.tensor(costs, device="cuda")
+        cold.waves = warm.waves = waves
+        warm.reset_warm_start()
+        its = []
+        for step in range(4):
+            a = cold.cone_op(ids, pred, MODE_INNER, -1.0, 0.2, outputs=ALL)
+            b = warm.cone_op(ids, pred, MODE_INNER, -1.0, 0.2, outputs=ALL)
+            for k in ALL:
+                tol = 4e-6 * (sc if k in ("proj", "rnorm") else 4.0)
+                assert float((a[k] - b[k]).abs().max()) <= tol, (waves, step, k)
+            its.append((float(a["iters"].float().mean()), float(b["iters"].float().mean())))
+            if step == 0:  # first call: nothing cached yet, identical work; and the fixture itself
+                assert torch.equal(a["iters"], b["iters"])
+                assert np.abs(b["proj"].cpu().numpy() - g["tsp20_min_proj"]).max() <= 2e-6 * sc
+            pred = pred + torch.tensor(rng.normal(0, 0.01, costs.shape).astype(np.float32), device="cuda")
+        assert its[-1][1] <= 3.0 and its[-1][1] < its[-1][0] - 1.5, its   # <= 3 iterations once warm
+    # a NaN prediction invalidates the entry instead of poisoning the cache
+    bad = pred.clone()
+    bad[2, 7] = float("nan")
+    o = warm.cone_op(ids, bad, MODE_INNER, -1.0, 0.2, check=False, outputs=("loss",))
+    assert int(o["status"][2]) == 3 and int(warm.t["warm_state"][2]) == 0 and int(warm.t["warm_state"][3]) == 1
+    o = warm.cone_op(ids, pred, MODE_INNER, -1.0, 0.2, outputs=ALL)
+    a = cold.cone_op(ids, pred, MODE_INNER, -1.0, 0.2, outputs=ALL)
+    assert float((a["proj"] - o["proj"]).abs().max()) <= 4e-6 * sc
+
+
+def test_training_harness_on_tsp_with_warm_start():
+    """examples/train_sp_cave.py --problem tsp: the code_sample.py loop on DFJ TSP cones built without Gurobi
+    (Held-Karp / HiGHS), packed store, warm start: regret drops and epochs >= 2 need <= 3 Newton iterations."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import train_sp_cave
+
+    hist = train_sp_cave.main(["--problem", "tsp", "--nodes", "9", "--num-data", "64", "--batch", "32", "--epochs", "6",
+                               "--packed", "--warm-start"])
+    assert hist[-1][2] < hist[0][2] and hist[-1][1] < hist[1][1], hist
+    log = train_sp_cave.main.iters_log
+    assert all(m <= 3.0 for m, _ in log[1:]), log

@@ -25,7 +25,10 @@ def timeit(fn, reps=40):
     torch.cuda.synchronize()
     t = np.array([a.elapsed_time(b) for a, b in ev]) * 1e3
     return np.median(t), t.min()
-for waves in (1, 2, 4, 8):
+from cave_amd import qpsolver
+cone_op_dense(bat[0][0], bat[0][1], 2, -1.0, 0.2, outputs=("loss", "grad"))  # checked: settles the auto shape
+print("auto dense form:", "split (slot pack + one-wave solve)" if qpsolver._split_ok.get((bat[0][0].shape[1], bat[0][0].shape[2])) else "fused")
+for waves in (0, 1, 2, 4, 8):
     def fd(i):
         c, p, _ = bat[i % R]
         return cone_op_dense(c, p, 2, -1.0, 0.2, waves=waves, check=False, outputs=("loss", "grad"))
