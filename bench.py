@@ -276,6 +276,11 @@ def main(argv=None):
         b.record()
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    from cave_amd import qpsolver
+
+    split = qpsolver._split_ok.get((m_max, d)) is True
+    kernels = ("cone_pack_kernel<4 waves> (slot mode: scan + cone build -> transient store) + "
+               "cone_packed_kernel<1 wave> (lite Newton solver + fused loss/grad)") if split else "cone_dense_kernel (fused)"
     # algorithmic bytes per launch, dense operator format: cone once, y once, outputs once
     alg = []
     for bids, _, _, _ in batches:
@@ -287,7 +292,7 @@ def main(argv=None):
     traffic, traffic_src = None, None  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/diag/pmc_run.sh)
     try:
         pm = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
-        if pm.get("workload") == f"tsp{args.tsp}_b{args.batch}_{args.mode}":
+        if pm.get("workload") == f"tsp{args.tsp}_b{args.batch}_{args.mode}" and pm.get("split") == split:
             traffic, traffic_src = pm.get("hbm_bytes_per_launch"), PMC_SUMMARY
     except Exception:  # noqa: BLE001
         pass
@@ -303,7 +308,9 @@ def main(argv=None):
                        "batch_per_gpu": B, "d": d, "m_max": m_max, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "cone_dense_kernel", "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                         "kernel": kernels, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                         "kernel_ms_note": "HIP events around one operator call = every kernel of the step (the split "
+                                           "form launches two); per-kernel durations: profiles/r02_kernel_stats.csv",
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),

@@ -24,7 +24,7 @@ _SOURCES = [
 
 # status / mode constants (include/cave_hip.h)
 ST_OK, ST_NOT_CONVERGED, ST_TOO_LARGE, ST_BAD_INPUT = 0, 1, 2, 3
-MODE_PROJECT, MODE_EXACT, MODE_INNER, MODE_HEURISTIC, MODE_AVG = 0, 1, 2, 3, 4
+MODE_PROJECT, MODE_EXACT, MODE_INNER, MODE_HEURISTIC, MODE_AVG, MODE_INNER_IPM = 0, 1, 2, 3, 4, 5
 MAX_LDS = 160 * 1024
 
 ABI_SYMBOLS = (

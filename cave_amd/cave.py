@@ -41,6 +41,11 @@ def _packed_kwargs(kwargs: dict) -> dict:
     return {k: v for k, v in kwargs.items() if k in ("max_iter", "check")}
 
 
+def _op_kwargs(kwargs: dict) -> dict:
+    """solver_kwargs minus the keys the loss modules consume themselves ('inner': the kind of interior point)."""
+    return {k: v for k, v in kwargs.items() if k != "inner"}
+
+
 # ---- deferred status checks (solver_kwargs={"check": "lazy"})
 # Reading the per-instance status back right after the launch costs a host sync per step, which exposes the launch
 # latency of everything else in an eager training step (0.54 -> 0.35 ms at TSP-20 / B = 1024).  In lazy mode the
@@ -85,6 +90,7 @@ class _ConeLossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred_cost, tight_ctrs, mode, sign, inner_ratio, kwargs):
+        kwargs = _op_kwargs(kwargs)
         lazy = kwargs.get("check") == "lazy"
         if lazy:
             flush_checks()  # the previous call's verdict
@@ -130,21 +136,24 @@ class abstractConeAlignedCosine(optModule):
     def forward(self, pred_cost: torch.Tensor, tight_ctrs: torch.Tensor) -> torch.Tensor:
         sign = sense_sign(self.optmodel.modelSense)  # ValueError on a bad sense, src/cave.py:62-67
         loss = _ConeLossFunction.apply(pred_cost, tight_ctrs, self._mode(), sign, self._inner_ratio(),
-                                       self.solver_kwargs)
+                                       self._solver_kwargs_for_call())
         return self._reduce(loss)
 
     def _inner_ratio(self) -> float:
         return 0.0
+
+    def _solver_kwargs_for_call(self) -> dict:
+        return self.solver_kwargs
 
     def _get_projection(self, signed_cost: torch.Tensor, tight_ctrs: torch.Tensor) -> torch.Tensor:
         """The constant target for an already sense-flipped cost (src/cave.py:121-129,197-219)."""
         with torch.no_grad():
             if isinstance(tight_ctrs, PackedBatch):
                 o = tight_ctrs.store.cone_op(tight_ctrs.ids, signed_cost, self._mode(), 1.0, self._inner_ratio(),
-                                             outputs=("target",), **_packed_kwargs(self.solver_kwargs))
+                                             outputs=("target",), **_packed_kwargs(self._solver_kwargs_for_call()))
             else:
                 o = cone_op_dense(tight_ctrs, signed_cost, self._mode(), 1.0, self._inner_ratio(),
-                                  outputs=("target",), **self.solver_kwargs)
+                                  outputs=("target",), **_op_kwargs(self._solver_kwargs_for_call()))
         return o["target"].to(device=signed_cost.device, dtype=signed_cost.dtype)
 
 
@@ -168,11 +177,17 @@ class exactConeAlignedCosine(abstractConeAlignedCosine):
 
 
 class innerConeAlignedCosine(exactConeAlignedCosine):
-    """CaVE+ / CaVE Hybrid (src/cave.py:132-219) with nnls-style push-inside targets.
+    """CaVE+ / CaVE Hybrid (src/cave.py:132-219).
 
-    `solver='hip'` is an exact projector like 'nnls', so the interior point comes from the convex
-    combination with the average normal (src/cave.py:216-219); ``max_iter`` is accepted for
-    signature compatibility and ignored exactly as the nnls arm ignores it (src/cave.py:302).
+    Default (``solver_kwargs`` without ``'inner'``, or ``{'inner': 'push'}``): `solver='hip'` is an exact
+    projector like 'nnls', so the interior point comes from the convex combination with the average normal
+    (src/cave.py:216-219); ``max_iter`` is then ignored exactly as the nnls arm ignores it (src/cave.py:302).
+
+    ``solver_kwargs={'inner': 'ipm'}``: the interior point is a truncated interior-point iterate, the way the
+    reference's CaVE+ uses Clarabel with ``max_iter`` iterations (src/cave.py:213-214, 267-295): ``max_iter``
+    path-following steps on the barrier problem (CAVE_MODE_INNER_IPM, include/cave_hip.h), every multiplier of
+    the iterate strictly positive, the normalised iterate is the target and no average normal is mixed in.
+    An emulation of the mechanism, not of Clarabel's iterates (no Clarabel in the image: parity unpinned).
     """
 
     _INNER_DEFAULTS: dict[str, dict] = {"hip": {}}
@@ -187,6 +202,9 @@ class innerConeAlignedCosine(exactConeAlignedCosine):
             raise ValueError(f"Invalid solve_ratio {solve_ratio}. It should be between 0 and 1.")
         if not 0 <= inner_ratio <= 1:
             raise ValueError(f"Invalid inner_ratio {inner_ratio}. It should be between 0 and 1.")
+        self.inner = str(self.solver_kwargs.get("inner", "push"))
+        if self.inner not in ("push", "ipm"):
+            raise ValueError(f"Invalid solver_kwargs['inner'] {self.inner!r}. It should be 'push' or 'ipm'.")
         self.max_iter = int(max_iter)
         self.solve_ratio = float(solve_ratio)
         self.inner_ratio = float(inner_ratio)
@@ -198,7 +216,12 @@ class innerConeAlignedCosine(exactConeAlignedCosine):
         # under data parallelism every rank must construct the module with the same seed
         if self._branch_rng.uniform() > self.solve_ratio:
             return _lib.MODE_HEURISTIC
-        return _lib.MODE_INNER
+        return _lib.MODE_INNER_IPM if self.inner == "ipm" else _lib.MODE_INNER
+
+    def _solver_kwargs_for_call(self) -> dict:
+        if self.inner == "ipm":  # max_iter is honoured: it is the number of interior-point steps
+            return dict(self.solver_kwargs, max_iter=max(1, self.max_iter))
+        return self.solver_kwargs
 
     def _inner_ratio(self) -> float:
         return self.inner_ratio

@@ -211,7 +211,7 @@ int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int
                             int32_t* status, int32_t* iters, void* stream) {
   if (B < 0 || m_max < 0 || d <= 0 || d > 65535) return fail(CAVE_E_INVALID, "cone_dense: bad shape (need 0 < d <= 65535)");
   if (m_max * d >= (int64_t)1 << 32) return fail(CAVE_E_INVALID, "cone_dense: m_max*d must be < 2^32");
-  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense: bad mode");
+  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_INNER_IPM) return fail(CAVE_E_INVALID, "cone_dense: bad mode");
   if (B == 0) return CAVE_OK;
   if (!ctrs && m_max > 0) return fail(CAVE_E_INVALID, "cone_dense: ctrs is null");
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense: pred is null");
@@ -219,7 +219,7 @@ int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int
   if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_dense: waves must be 0, 1, 2, 4 or 8");
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
-  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
+  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100);
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   CAVE_LAUNCH(cone_dense_kernel, waves, B, lds_bytes, stream, P, "cone_dense_kernel");
@@ -273,14 +273,15 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
                              int32_t waves, float* proj, float* rnorm, float* target, float* loss, float* grad,
                              int32_t* status, int32_t* iters, void* stream) {
   if (!store || B < 0) return fail(CAVE_E_INVALID, "cone_packed: null store / bad B");
-  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed: bad mode");
+  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_INNER_IPM) return fail(CAVE_E_INVALID, "cone_packed: bad mode");
   if (B == 0) return CAVE_OK;
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed: pred is null");
   if (lds_bytes <= 0 || (uint32_t)lds_bytes > kMaxLds) return fail(CAVE_E_INVALID, "cone_packed: bad lds_bytes");
   if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_packed: waves must be 0, 1, 2, 4 or 8");
   PackedParams P;
   P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
-  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
+  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100);
+  P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   CAVE_LAUNCH(cone_packed_kernel, waves, B, lds_bytes, stream, P, "cone_packed_kernel");
   return CAVE_OK;

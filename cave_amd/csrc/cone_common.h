@@ -62,6 +62,8 @@ enum : int32_t {
   MODE_INNER = 2,      // innerConeAlignedCosine QP branch (nnls) src/cave.py:206-219
   MODE_HEURISTIC = 3,  // innerConeAlignedCosine heuristic branch src/cave.py:201-204
   MODE_AVG = 4,        // _average_ctrs only                      src/cave.py:222-228
+  MODE_IPM = 5,        // innerConeAlignedCosine, truncated interior-point iterate as the target (CaVE+ with an
+                       // interior-point solver: src/cave.py:213-214,267-295; emulation, parity unpinned)
 };
 
 // reference thresholds

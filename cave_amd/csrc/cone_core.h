@@ -1212,6 +1212,155 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
                : solve_cone_impl<C, false, BAND>(c, v, w, max_iter, tol);
 }
 
+// ------------------------------------------------- truncated interior-point projection (MODE_IPM)
+//
+// The reference's CaVE+ runs an interior-point QP solver (Clarabel) for max_iter = 3 iterations and uses the
+// strictly interior iterate as the cone-aligned target (src/cave.py:213-214, 267-295).  Emulation (Clarabel is
+// not in the image: parity unpinned, tested by properties): primal path-following on
+//     min_{lam > 0}  1/2 || y - A^T lam ||^2  -  tau * sum_i log lam_i .
+// The multiplier of a signed-unit row appears in one coordinate only and is eliminated in closed form: for a
+// coordinate with a +e_k row and s = y_k - (M^T theta)_k,  mu = (s + sqrt(s^2 + 4 tau)) / 2 > 0  and the residual
+// becomes rho(s) = (s - sqrt(s^2 + 4 tau)) / 2 -- the Chen-Harker-Kanzow-Smale smoothing of min(s, 0) (mirrored
+// for -e_k).  What is left is smooth and strictly convex in the reduced multipliers theta:
+//     F_tau(theta) = sum_k psi_tau(s_k)  -  tau * sum_{i inequality} log theta_i ,     psi_tau' = rho ,
+//     grad = -M rho - tau / theta ,      Hessian = M diag(rho') M^T + tau diag(1 / theta^2) .
+// The bounds theta_i >= 0 of the inequality rows are handled PRIMAL-DUAL (a primal barrier step jams at the
+// boundary once tau is small): duals z_i > 0 with theta_i z_i = tau; one Newton step on the perturbed KKT system
+//     (H + diag(z / theta)) dtheta = M rho + tau / theta ,   dz = tau / theta - z - (z / theta) dtheta ,
+// fraction-to-the-boundary step lengths (0.995) for theta and z, then tau = 0.2 * mean(theta_i z_i) (Mehrotra-
+// style centring from the current complementarity, also covering the unit rows through the same tau).
+// Rows of a +a / -a pair and coordinates with both unit rows carry two multipliers whose barrier has no
+// minimiser (only their difference enters); they are left free, as an interior-point code's regularisation would.
+// On return w.res holds rho (so proj = y - rho = A^T lam of the iterate) and f = 1/2 ||rho||^2.
+template <class C, bool PM1>
+CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, int steps) {
+  const int NT = C::NT;
+  const int p = v.p, d = v.d, ldh = w.ldh;
+  double* theta = w.theta;
+  double* r = w.res;
+  double* rc = w.rc;
+  float* wgt = w.wold;
+  SolveResult out;
+  out.iters = 0;
+  out.status = ST_OK;
+  double yy = 0.0, ymax = 0.0;
+  for (int k = c.tid(); k < d; k += NT) {
+    yy += (double)w.y[k] * (double)w.y[k];
+    ymax = fmax(ymax, fabs((double)w.y[k]));
+  }
+  yy = c.reduce_sum(yy);
+  ymax = c.reduce_max(ymax);
+  double tau = 0.1 * ymax * ymax;
+  if (!(tau > 0.0)) tau = 1e-300;
+  const double tau_min = fmax(1e-14 * ymax * ymax, 1e-300);
+  double* z = w.ttry;
+  uint32_t nineq = 0;
+  for (int i = c.tid(); i < p; i += NT) {
+    theta[i] = v.vkind[i] ? 0.0 : sqrt(tau);
+    z[i] = v.vkind[i] ? 0.0 : sqrt(tau);
+    w.act[i] = 0;
+    nineq += v.vkind[i] ? 0u : 1u;
+  }
+  nineq = c.reduce_add_u32(nineq);
+  c.sync();
+  auto smooth_residual = [&](double t) {  // r -> rho (rc) and rho' (wgt); returns 1/2 ||rho||^2
+    double acc = 0.0;
+    for (int k = c.tid(); k < d; k += NT) {
+      const uint8_t u = v.usign[k];
+      const double s = r[k];
+      const double q = sqrt(s * s + 4.0 * t);
+      double rho = s, dr = 1.0;
+      if (u == 1) { rho = 0.5 * (s - q); dr = 0.5 * (1.0 - s / q); }
+      else if (u == 2) { rho = 0.5 * (s + q); dr = 0.5 * (1.0 + s / q); }
+      else if (u == 3) { rho = 0.0; dr = 0.0; }
+      rc[k] = rho;
+      wgt[k] = (float)dr;
+      acc += rho * rho;
+    }
+    const double f = 0.5 * c.reduce_sum(acc);
+    c.sync();
+    return f;
+  };
+  int it = 0;
+  for (; it < steps && p > 0; ++it) {
+    gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+    smooth_residual(tau);
+    gradient<C, PM1>(c, v, rc, w.g);  // g = -M rho
+    for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+    c.sync();
+    for (int k = c.tid(); k < d; k += NT) {
+      const double wk = (double)wgt[k];
+      if (!(wk > 0.0)) continue;
+      const uint32_t lo = v.cptr[k], hi = v.cptr[k + 1];
+      for (uint32_t e1 = lo; e1 < hi; ++e1) {
+        uint32_t a, b;
+        double v1, v2;
+        csc_entry<PM1>(v, e1, a, v1);
+        const double va = wk * v1;
+        c.atomic_add_f64(&w.H[a * ldh + a], va * v1);
+        for (uint32_t e2 = lo; e2 < e1; ++e2) {
+          csc_entry<PM1>(v, e2, b, v2);
+          const double vv = va * v2;
+          c.atomic_add_f64(&w.H[a * ldh + b], vv);
+          c.atomic_add_f64(&w.H[b * ldh + a], vv);
+        }
+      }
+    }
+    c.sync();
+    for (int i = c.tid(); i < p; i += NT) {
+      double rhs = -w.g[i];
+      if (!v.vkind[i]) {
+        const double inv = 1.0 / theta[i];
+        rhs += tau * inv;
+        w.H[i * ldh + i] += z[i] * inv;
+      }
+      w.g2[i] = rhs;
+    }
+    c.sync();
+    c.solve_spd(w.H, ldh, w.g2, w.act, p, 1e-12, w.step);
+    c.sync();
+    double ap = 1e300, ad = 1e300;
+    for (int i = c.tid(); i < p; i += NT) {
+      double dz = 0.0;
+      if (!v.vkind[i]) {
+        const double inv = 1.0 / theta[i];
+        dz = tau * inv - z[i] - z[i] * inv * w.step[i];
+        if (w.step[i] < 0.0) ap = fmin(ap, -theta[i] / w.step[i]);
+        if (dz < 0.0) ad = fmin(ad, -z[i] / dz);
+      }
+      w.told[i] = dz;
+    }
+    ap = -c.reduce_max(-ap);
+    ad = -c.reduce_max(-ad);
+    const double alpha_p = fmin(1.0, 0.995 * ap), alpha_d = fmin(1.0, 0.995 * ad);
+    double gap = 0.0;
+    for (int i = c.tid(); i < p; i += NT) {
+      theta[i] += alpha_p * w.step[i];
+      z[i] += alpha_d * w.told[i];
+      gap += theta[i] * z[i];
+    }
+    gap = c.reduce_sum(gap);
+    tau = nineq > 0u ? 0.2 * gap / (double)nineq : 0.2 * tau;
+    // floor: the smoothed problem must stay smooth enough for plain Newton steps (the smoothing error of the
+    // iterate is ~sqrt(tau) = 1e-7 max|y| there, below float32 resolution)
+    if (!(tau > tau_min)) tau = tau_min;
+    c.sync();
+  }
+  gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+  const double f = smooth_residual(tau);
+  for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];
+  c.sync();
+  if (!(f == f) || !(yy == yy)) out.status = ST_BAD_INPUT;
+  out.f = f;
+  out.iters = it;
+  return out;
+}
+
+template <class C>
+CAVE_HD SolveResult solve_cone_ipm(C& c, const SolveView& v, SolveWork& w, int steps) {
+  return v.pm1 ? solve_cone_ipm_impl<C, true>(c, v, w, steps) : solve_cone_ipm_impl<C, false>(c, v, w, steps);
+}
+
 // half bandwidth of M M^T in the reduced-row order: the widest span of reduced rows meeting in one
 // column (CSC columns are sorted by reduced-row index)
 template <class C>
@@ -1278,7 +1427,7 @@ CAVE_HD void epilogue(C& c, int mode, int d, float sign, float inner_ratio, bool
   const bool inside = rn < kInsideRnorm;  // src/cave.py:218
   for (int k = c.tid(); k < d; k += NT) {
     double t;
-    if (mode == MODE_EXACT) t = tvec[k] / np_c;                                  // :129
+    if (mode == MODE_EXACT || mode == MODE_IPM) t = tvec[k] / np_c;              // :129, :211-214
     else if (mode == MODE_INNER) {
       double pn = tvec[k] / np_c;                                                // :211
       t = inside ? pn : (1.0 - r) * pn + r * (double)avg[k];                      // :216-219

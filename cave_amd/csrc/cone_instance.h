@@ -142,7 +142,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
                                  const OutPtrs& o, int* iters_out, float* warm_theta = nullptr,
                                  uint8_t* warm_state = nullptr) {
   const int d = v.d;
-  const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER);
+  const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER || mode == MODE_IPM);
   int32_t st = ST_OK;
   double f = 0.0;
   const bool empty = (v.n_valid == 0);
@@ -160,6 +160,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     SolveWork w;
     w.y = y;
     w.bw = 0; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
+    if (mode == MODE_IPM) { warm_theta = nullptr; warm_state = nullptr; }  // the interior iterate is not a starting point
     w.warm = (warm_theta && warm_state && *warm_state == 1) ? warm_theta : nullptr;
     if constexpr (LARGE) {
       const int bw = band_halfwidth(c, v);
@@ -231,8 +232,13 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     c.sync();
     SolveResult r;
     bool lite = false;
+    if constexpr (LARGE) { if (mode == MODE_IPM) return ST_BAD_INPUT; }  // rejected by the host entry points
+    else if (mode == MODE_IPM) {
+      r = solve_cone_ipm(c, vv, w, max_iter);
+      lite = true;  // (handled)
+    }
 #if defined(__HIPCC__)
-    if constexpr (!LARGE && C::NWAVES == 1) {
+    if constexpr (!LARGE && C::NWAVES == 1) if (!lite) {
       // small +-1 cone on a one-wave workgroup: Newton iteration over the lite index structures (cone_core.h).
       // (Only the one-wave kernels carry this path: it wants ~200 VGPRs, and inlined into the 4-wave kernels,
       // whose residency rests on a 128-VGPR budget, it cost 650 bytes of scratch per lane.)
@@ -397,7 +403,7 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
     const int p = S.n_rows ? (int)S.n_rows[slot] : (int)(S.row_off[slot + 1] - r0);
     const uint32_t nz = S.n_nnz ? (uint32_t)S.n_nnz[slot] : (uint32_t)(S.nnz_off[slot + 1] - z0);
     const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
-    const bool need_proj = (P.mode == MODE_PROJECT || P.mode == MODE_EXACT || P.mode == MODE_INNER);
+    const bool need_proj = (P.mode == MODE_PROJECT || P.mode == MODE_EXACT || P.mode == MODE_INNER || P.mode == MODE_IPM);
     float* y = ar.get<float>(d);
     float* avg = need_avg ? ar.get<float>(d) : nullptr;
     uint8_t* usign = ar.get<uint8_t>(d);

@@ -57,6 +57,14 @@ extern "C" {
 #define CAVE_MODE_INNER 2
 #define CAVE_MODE_HEURISTIC 3
 #define CAVE_MODE_AVG 4
+/* CaVE+ with a truncated interior-point projection (src/cave.py:213-214, 267-295: the reference runs Clarabel
+ * with max_iter = 3 and uses the strictly interior iterate, normalised, as the target).  Here: `max_iter`
+ * steps (<= 0: 3) of a primal path-following method on  min 1/2 ||y - A^T lam||^2 - tau * sum log lam_i  with
+ * tau shrinking every step; the multipliers of the signed-unit rows are eliminated in closed form, which turns
+ * their clip into its Chen-Harker-Kanzow-Smale smoothing.  Every multiplier of the iterate is > 0; proj / rnorm
+ * are those of the iterate and tend to the exact projection as max_iter grows.  An emulation: Clarabel's own
+ * iterates are not reproduced (no Clarabel in the image: parity unpinned).  Fast path only (not *_large). */
+#define CAVE_MODE_INNER_IPM 5
 
 int32_t cave_hip_version(void);
 /* thread-local, valid until the next failing call on this thread */
@@ -83,7 +91,7 @@ int32_t cave_hip_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int3
  *   pred  [B, d]        float32; the kernel works on y = sign * pred
  *   mode  CAVE_MODE_*;  sign  -1 (EPO.MINIMIZE) / +1 (EPO.MAXIMIZE); for PROJECT pass +1
  *   inner_ratio  weight of the average normal (INNER, HEURISTIC)
- *   max_iter     Newton iteration cap (<=0: default 100)
+ *   max_iter     Newton iteration cap (<=0: default 100); CAVE_MODE_INNER_IPM: interior-point steps (<=0: 3)
  * Outputs (any may be NULL):
  *   proj   [B, d]  projection of y onto cone{lam @ ctrs_b : lam >= 0}
  *   rnorm  [B]     ||y - proj||_2 (un-squared, nnls convention)

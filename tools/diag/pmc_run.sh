@@ -3,9 +3,9 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof4
+OUT=$R/gpurun_out/${PROF_DIR:-prof_r02}
 mkdir -p $OUT
-CMD="python3 $R/bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-extras"
+CMD="python3 $R/bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-extras ${BENCH_ARGS:-}"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.json 2> $OUT/trace.err || echo "trace failed"
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || echo "pmc fetch failed"
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err || echo "pmc write failed"
