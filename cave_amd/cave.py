@@ -187,7 +187,7 @@ class innerConeAlignedCosine(exactConeAlignedCosine):
     reference's CaVE+ uses Clarabel with ``max_iter`` iterations (src/cave.py:213-214, 267-295): ``max_iter``
     path-following steps on the barrier problem (CAVE_MODE_INNER_IPM, include/cave_hip.h), every multiplier of
     the iterate strictly positive, the normalised iterate is the target and no average normal is mixed in.
-    An emulation of the mechanism, not of Clarabel's iterates (no Clarabel in the image: parity unpinned).
+    A restatement of the mechanism, not of Clarabel's iterates (no Clarabel in the image: parity unpinned).
     """
 
     _INNER_DEFAULTS: dict[str, dict] = {"hip": {}}
