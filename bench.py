@@ -126,6 +126,27 @@ def _oracle_chunk(job):
     return len(y)
 
 
+def _host_cores() -> int:
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show
+    every core of the host in the mask but grant a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return n
+
+
 def cpu_baseline(ctrs_np, signed_np, n_sample, label):
     """The CPU restatement of the reference's nnls path (oracle/nnls_oracle.c, Lawson-Hanson, fp64) in the
     reference's loop shape: serial (`processes=1`, src/cave.py:257) and over all host cores (the
@@ -140,7 +161,7 @@ def cpu_baseline(ctrs_np, signed_np, n_sample, label):
     t0 = time.perf_counter()
     O.batch_project(signed_np[:n], ctrs_np[:n])
     dt = time.perf_counter() - t0
-    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nproc = _host_cores()
     out = {"value": n / dt, "unit": "projections/s", "cores": 1, "kind": "port",
            "sample": f"{n} {label} instances of the benchmark batch, serial loop, {dt:.1f} s"}
     if nproc > 1:
@@ -444,6 +465,37 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
     flush_checks()
     torch.cuda.synchronize()
     out["train_step_lazy_check_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+    # the same steps with the store's warm start (multipliers of the previous solve of each instance): cones are
+    # static and the predictor moves a little per Adam step
+    wstore = ConeStore.from_dense(torch.tensor(ctrs_np))
+    wstore.enable_warm_start()
+    wbatch = PackedBatch(wstore, tid)
+
+    def train_step_warm():
+        loss = cave_lazy(reg(x), wbatch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    for _ in range(5):
+        train_step_warm()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = []
+    for _ in range(50):
+        train_step_warm()
+        its.append(wstore.last_iters)
+    flush_checks()
+    torch.cuda.synchronize()
+    out["train_step_warm_start_lazy_check_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+    out["train_step_warm_start_newton_iters_mean"] = float(torch.stack(its).float().mean())
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in kev:
+        a.record()
+        wstore.cone_op(tid, reg(x).detach(), mode, -1.0, 0.2, check=False, outputs=outs)
+        b.record()
+    torch.cuda.synchronize()
+    out["packed_store_warm_start_kernel_ms"] = float(np.mean([a.elapsed_time(b) for a, b in kev]))
     # the same step captured in a HIP graph (the C-ABI launch path does no allocation, attribute
     # change or host sync of its own when status checking is deferred)
     try:

@@ -25,8 +25,9 @@
 // Cycle deltas are summed in per-wave registers (WaveCtx::st) and stored once per instance.
 #if defined(CAVE_STAMPS) && defined(__HIPCC__)
 #define CAVE_T0() unsigned long long _t0 = __builtin_amdgcn_s_memtime()
-#define CAVE_ACC(slot) do { unsigned long long _t1 = __builtin_amdgcn_s_memtime(); \
-    c.st[slot] += _t1 - _t0; _t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define CAVE_ACC(slot) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    unsigned long long _t1 = __builtin_amdgcn_s_memtime(); \
+    c.st[slot] += _t1 - _t0; _t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define CAVE_T0() do {} while (0)
 #define CAVE_ACC(slot) do {} while (0)

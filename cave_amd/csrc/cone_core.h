@@ -622,6 +622,7 @@ __device__ __forceinline__ void lite_hessian(C& c, const LiteCone& L, const Solv
   const float imu = (float)inv_mu;
 #pragma unroll
   for (int s = 0; s < KC; ++s) {
+    if (64 * s >= d) continue;  // wave-uniform: no coordinate in this slot
     const int k = lane + 64 * s;
     const uint32_t u = us[s];
     const float t = (u == 2u) ? (float)rk[s] : -(float)rk[s];  // > 0 on the side that carries residual
@@ -798,6 +799,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   CAVE_T0();
   for (; p > 0 && it < max_iter; ++it, cap07 *= 0.7, sched01 *= 0.1) {
     // gradient g = -M Pi(r) and projected-gradient norm
+    CAVE_ACCF(22);
     gradient_any<C, PM1>(c, v, rc, w.g);
     CAVE_ACCF(16);
     // Zig-zag extrapolation.  On degenerate cones (duplicated generators, y inside the cone) the iteration can
@@ -1087,8 +1089,14 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       psi0 += w.g[i] * di;
       if (!v.vkind[i] && di < 0.0) amax = fmin(amax, theta[i] / (-di));
     }
-    psi0 = c.reduce_sum(psi0);
-    amax = -c.reduce_max(-amax);  // >= 1 because tc is feasible
+    if constexpr (ctx_lite<C>::value) {  // one interleaved pass for both
+      double nm = -amax;
+      c.reduce_sum_max(psi0, nm);
+      amax = -nm;
+    } else {
+      psi0 = c.reduce_sum(psi0);
+      amax = -c.reduce_max(-amax);  // >= 1 because tc is feasible
+    }
     if (amax < 1.0) amax = 1.0;
     c.sync();
     CAVE_ACCF(21);
@@ -1210,6 +1218,14 @@ template <class C, bool BAND = false>
 CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol) {
   return v.pm1 ? solve_cone_impl<C, true, BAND>(c, v, w, max_iter, tol)
                : solve_cone_impl<C, false, BAND>(c, v, w, max_iter, tol);
+}
+
+// The large-cone path calls the Newton iteration as a REAL function: inlined next to the streaming scan and the
+// cone build of the persistent large kernels it inherited (and added to) a register file that spilled 150-250
+// VGPRs; as a function it gets its own allocation and only the call boundary saves registers.
+template <class C>
+CAVE_NOINLINE void solve_cone_band_call(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol, SolveResult* out) {
+  *out = solve_cone<C, true>(c, v, w, max_iter, tol);
 }
 
 // ------------------------------------------------- truncated interior-point projection (MODE_IPM)

@@ -238,29 +238,37 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       lite = true;  // (handled)
     }
 #if defined(__HIPCC__)
-    if constexpr (!LARGE && C::NWAVES == 1) if (!lite) {
-      // small +-1 cone on a one-wave workgroup: Newton iteration over the lite index structures (cone_core.h).
-      // (Only the one-wave kernels carry this path: it wants ~200 VGPRs, and inlined into the 4-wave kernels,
-      // whose residency rests on a 128-VGPR budget, it cost 650 bytes of scratch per lane.)
-      // (a latency design: beyond ~2 instances per SIMD the general path's lower instruction count wins --
-      //  packed TSP-20 at B = 4096: 374 us with the lite solver)
+    if constexpr (!LARGE && C::LITE_OK) if (!lite) {
+      // small +-1 cone: Newton iteration on ONE wave over the lite index structures (cone_core.h).  Carried by
+      // the kernel shapes with a 256-register budget (one and two waves per instance: it wants ~200 VGPRs, and
+      // inlined into the 4-wave kernels, whose residency rests on 128, it cost 650 bytes of scratch per lane).
+      // In the two-wave shape wave 1 helps with the scan and the build, then parks at the barrier below.
+      // (A latency design: beyond ~2 instances per SIMD the general path's lower instruction count wins --
+      //  packed TSP-20 at B = 4096: 374 us with the lite solver.)
       LiteCone L;
       lite = gridDim.x <= 2048u && lite_build(c, ar, vv, L);
       if (lite) {
-        SoloCtx<32, 4> sc;
-        sc.lane = c.lane_id();
-        sc.lite = L;
+        r.f = 0.0; r.iters = 0; r.status = ST_OK;
+        if (c.wave_id() == 0) {
+          SoloCtx<32, 4> sc;
+          sc.lane = c.lane_id();
+          sc.lite = L;
 #ifdef CAVE_STAMPS
-        sc.st = c.st;
+          sc.st = c.st;
 #endif
-        r = solve_cone_impl<SoloCtx<32, 4>, true, false>(sc, vv, w, max_iter, 1e-11);
+          r = solve_cone_impl<SoloCtx<32, 4>, true, false>(sc, vv, w, max_iter, 1e-11);
 #ifdef CAVE_STAMPS
-        c.st[13] += 1000000;  // diagnostic marker: the lite path ran
+          c.st[13] += 1000000;  // diagnostic marker: the lite path ran
 #endif
+        }
+        c.broadcast_from_wave0(r.f, r.iters, r.status);
       }
     }
 #endif
-    if (!lite) r = solve_cone<C, LARGE>(c, vv, w, max_iter, 1e-11);
+    if (!lite) {
+      if constexpr (LARGE) solve_cone_band_call(c, vv, w, max_iter, 1e-11, &r);
+      else r = solve_cone<C, false>(c, vv, w, max_iter, 1e-11);
+    }
     st = r.status;
     f = r.f;
     *iters_out = r.iters;

@@ -41,7 +41,8 @@ struct SoloCtx {
   __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
   __device__ __forceinline__ void sync() const { asm volatile("" ::: "memory"); }
   __device__ __forceinline__ double reduce_sum(double v) const { return wave_sum_f64(v); }
-  __device__ __forceinline__ void reduce_sum2(double& a, double& b) const { a = wave_sum_f64(a); b = wave_sum_f64(b); }
+  __device__ __forceinline__ void reduce_sum2(double& a, double& b) const { wave_reduce2_f64<false>(a, b); }
+  __device__ __forceinline__ void reduce_sum_max(double& s, double& m) const { wave_reduce2_f64<true>(s, m); }
   __device__ __forceinline__ double reduce_max(double v) const { return wave_max_f64(v); }
   __device__ __forceinline__ uint32_t reduce_add_u32(uint32_t v) const { return wave_sum_u32(v); }
   __device__ __forceinline__ double team_reduce_sum(double v) const { return quad_sum_f64(v); }
@@ -62,6 +63,7 @@ struct BlockCtx {
   static constexpr int PMAX = (NW <= 2 || WIDE) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2 (or WIDE)
   static constexpr int MIN_WAVES_PER_EU = WIDE ? 1 : (NW <= 2 ? NW : 4);
   static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
+  static constexpr bool LITE_OK = (NW == 2 && !WIDE);  // 256-register budget at full residency (two waves per SIMD)
   struct Scratch {
     double f64[2][8];
     uint32_t u32[2][8];
@@ -82,6 +84,13 @@ struct BlockCtx {
     wave = t >> 6;
     par = 0;
     sc = reinterpret_cast<Scratch*>(smem);
+  }
+  // hand three words from wave 0 to the whole workgroup (one barrier)
+  __device__ __forceinline__ void broadcast_from_wave0(double& a, int& b, int& c) {
+    if (t == 0) { sc->f64[par][0] = a; sc->u32[par][0] = (uint32_t)b; sc->u32[par][1] = (uint32_t)c; }
+    __syncthreads();
+    a = sc->f64[par][0]; b = (int)sc->u32[par][0]; c = (int)sc->u32[par][1];
+    par ^= 1u;
   }
   __device__ __forceinline__ int tid() const { return t; }
   __device__ __forceinline__ int wave_id() const { return wave; }

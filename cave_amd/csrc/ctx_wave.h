@@ -17,6 +17,7 @@ struct WaveCtx {
   static constexpr int KREG = 4;         // line search keeps r, q in registers when d <= KREG * NT
   static constexpr uint32_t SCRATCH_BYTES = 0;
   static constexpr int NWAVES = 1;       // waves per instance
+  static constexpr bool LITE_OK = true;  // 256-register budget: carries the one-wave lite solver (cone_core.h)
   static constexpr int MIN_WAVES_PER_EU = 2;  // 256 registers: two one-wave workgroups per SIMD (B > 1024 keeps latency hiding)
   static constexpr int WL = 64;          // lanes per wave
   int lane;
@@ -24,6 +25,7 @@ struct WaveCtx {
   unsigned long long st[16];
 #endif
   __device__ __forceinline__ void init(unsigned char*) { lane = (int)threadIdx.x; }
+  __device__ __forceinline__ void broadcast_from_wave0(double&, int&, int&) const {}
   __device__ __forceinline__ int tid() const { return lane; }
   __device__ __forceinline__ int wave_id() const { return 0; }
   __device__ __forceinline__ int lane_id() const { return lane; }

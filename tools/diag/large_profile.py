@@ -1,0 +1,26 @@
+"""Workload for rocprofv3: BASELINE configs 3 / 4 at their per-GPU batch on the packed store, every batch slot a
+DISTINCT cone (coordinate-form generator, densified on the GPU a chunk at a time).
+    python tools/diag/large_profile.py tsp100|sp30 [B] [steps]"""
+import sys, os, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from cave_amd import synth, _lib
+from cave_amd.dataset import ConeStore
+which = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (512 if which == "tsp100" else 1024)
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+dev = torch.device("cuda")
+kind, size, chunk = ("tsp", 100, 4) if which == "tsp100" else ("sp", (30, 30), 32)
+items, costs, _ = synth.coo_batch(kind, size, B, seed=0)
+d = costs.shape[1]; m_max = max(it[3] for it in items)
+store = ConeStore.from_chunks_lazy(lambda i: synth.densify_on(items[i:i + chunk], d, dev, m_max), list(range(0, B, chunk)))
+ids = torch.arange(B, device=dev)
+pred = torch.tensor(costs, device=dev) + 0.05 * torch.randn(B, d, device=dev)
+o = store.cone_op(ids, pred, _lib.MODE_INNER, -1.0, 0.2, outputs=("loss", "grad"))
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(steps): store.cone_op(ids, pred, _lib.MODE_INNER, -1.0, 0.2, check=False, outputs=("loss", "grad"))
+torch.cuda.synchronize()
+dt = (time.time() - t0) / steps
+print(f"{which} B={B} distinct cones: {dt*1e3:.2f} ms/step, {B/dt:.0f} proj/s, iters mean {o['iters'].float().mean():.2f} max {int(o['iters'].max())}, "
+      f"rows {store.max_rows} bw {store.max_bw} algorithmic bytes {store.algorithmic_bytes(ids)}")

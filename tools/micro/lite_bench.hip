@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void k(const float* ctrs, const float* pred, in
   t[7] = __builtin_amdgcn_s_memtime();
   for (int r = 0; r < reps; ++r) { double a = sc.reduce_sum(g[threadIdx.x & 31]); double bb = sc.reduce_max(dv[threadIdx.x & 31]); if (a + bb == 1.2345) g[1] = a; }
   t[8] = __builtin_amdgcn_s_memtime();
-  SolveWork w; w.H = H; w.ldh = 33; w.wold = wold;
+  SolveWork w; w.H = H; w.ldh = 33; w.wold = wold; w.warm = nullptr;
   unsigned long long th0 = 0, th1 = 0;
   for (int r = 0; r < reps; ++r) {
     for (int kx = c.tid(); kx < d; kx += 64) wold[kx] = 0.f;   // every coordinate with weight > 0 changes
@@ -101,6 +101,18 @@ __global__ __launch_bounds__(64) void k(const float* ctrs, const float* pred, in
   unsigned long long s0 = __builtin_amdgcn_s_memtime();
   SolveResult sr = solve_cone_impl<SoloCtx<32, 4>, true, false>(sc, v, w, 100, 1e-11);
   unsigned long long s1 = __builtin_amdgcn_s_memtime();
+  {  // the general one-wave solver on the same instance: same minimum, comparable iteration count
+    double fl = sr.f; int il = sr.iters;
+    SolveView vg = v;
+    uint8_t* lflag = ar.get<uint8_t>(40); uint32_t* llist = ar.get<uint32_t>(40);
+    for (int i = c.tid(); i < p; i += 64) lflag[i] = (uint8_t)((v.mptr[i + 1] - v.mptr[i]) > kLongRow ? 1 : 0);
+    c.sync();
+    vg.nlong = (int)c.compact_nonzero_u8(lflag, p, llist); vg.longrow = llist;
+    c.sync();
+    SolveResult sg = solve_cone_impl<WaveCtx, true, false>(c, vg, w, 100, 1e-11);
+    if (threadIdx.x == 0 && (fabs(sg.f - fl) > 1e-9 * (1.0 + fabs(sg.f)) || sg.iters != il || sr.status != 0))
+      printf("block %d: lite f %.12e iters %d status %d | general f %.12e iters %d\n", b, fl, il, sr.status, sg.f, sg.iters);
+  }
   // cross-check: lite vs general results
   lite_gradient(sc, L, p, rc, g); double gl = threadIdx.x < p ? g[threadIdx.x] : 0.0;
   gradient<SoloCtx<32, 4>, true>(sc, v, rc, g); double gg = threadIdx.x < p ? g[threadIdx.x] : 0.0;
@@ -149,7 +161,7 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> o2((size_t)B * 32);
   hipMemcpy(o2.data(), dout2, o2.size() * 8, hipMemcpyDeviceToHost);
   const char* sn[32] = {"", "", "pgn loop + reduce + test", "hessian", "rhs / moved / misc", "solve_spd", "ls: q", "ls: exact_step", "ls: residual update, f", "",
-                        "", "", "", "", "", "", "gradient", "zig-zag / told copy", "attempt setup", "ratio test + reduce", "inner update loop", "psi0 / amax + reduces"};
+                        "", "", "", "", "", "", "gradient", "zig-zag / told copy", "attempt setup", "ratio test + reduce", "inner update loop", "psi0 / amax + reduces", "loop top (before gradient)"};
   double its = 0; for (int b = 0; b < B; ++b) its += o[(size_t)b * NSLOT + 15];
   for (int sidx = 0; sidx < 32; ++sidx) {
     double sum = 0; for (int b = 0; b < B; ++b) sum += o2[(size_t)b * 32 + sidx];
