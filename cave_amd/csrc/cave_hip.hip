@@ -215,8 +215,10 @@ int32_t cave_hip_cone_dense(const float* ctrs, const float* pred, int64_t B, int
   if (B == 0) return CAVE_OK;
   if (!ctrs && m_max > 0) return fail(CAVE_E_INVALID, "cone_dense: ctrs is null");
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense: pred is null");
-  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "cone_dense: bad nnz_cap / lds_bytes");
   if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "cone_dense: waves must be 0, 1, 2, 4 or 8");
+  // the one-wave lite solver only exists in the one- / two-wave shapes and only runs for grids of up to 2048
+  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes, waves <= 2 && B <= 2048))
+    return fail(CAVE_E_INVALID, "cone_dense: bad nnz_cap / lds_bytes");
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
   P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100);
@@ -232,7 +234,7 @@ int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t
     return fail(CAVE_E_INVALID, "pack_count: bad shape");
   if (B == 0) return CAVE_OK;
   if (!ctrs || !n_rows || !n_nnz) return fail(CAVE_E_INVALID, "pack_count: null pointer");
-  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "pack_count: bad limits");
+  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes, false)) return fail(CAVE_E_INVALID, "pack_count: bad limits");
   if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_count: waves must be 0, 1, 2, 4 or 8");
   PackParams P;
   memset(&P, 0, sizeof(P));
@@ -250,7 +252,7 @@ int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t 
   if (B == 0) return CAVE_OK;
   if (!ctrs || !store) return fail(CAVE_E_INVALID, "pack_fill: null pointer");
   if (store->d != d || slot0 < 0 || slot0 + B > store->n) return fail(CAVE_E_INVALID, "pack_fill: store mismatch");
-  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes)) return fail(CAVE_E_INVALID, "pack_fill: bad limits");
+  if (!resolve_limits(m_max, d, nnz_cap, lds_bytes, false)) return fail(CAVE_E_INVALID, "pack_fill: bad limits");
   if (!waves_ok(waves)) return fail(CAVE_E_INVALID, "pack_fill: waves must be 0, 1, 2, 4 or 8");
   PackParams P;
   memset(&P, 0, sizeof(P));
@@ -264,7 +266,7 @@ int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t 
 
 int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1) {
   if (d <= 0 || max_rows < 0 || max_nnz < 0) return CAVE_E_INVALID;
-  int32_t s = packed_lds_bytes(d, max_rows, max_nnz, all_pm1 != 0);
+  int32_t s = packed_lds_bytes(d, max_rows, max_nnz, all_pm1 != 0, all_pm1 != 2);
   return s < 0 ? CAVE_E_INVALID : s;
 }
 

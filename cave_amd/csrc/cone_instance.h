@@ -520,8 +520,10 @@ static constexpr uint32_t kMaxLds = 160u * 1024u;
 // Upper bound of the arena a dense launch needs, assuming at most `rows_raw` general rows,
 // `p` reduced rows and `nnzM` reduced non-zeros (the kernel reports ST_TOO_LARGE otherwise).
 // `nt` = threads per workgroup (per-thread dump slots of the scan), `pm1` = +-1 cones (no value arrays).
+// `lite_room`: reserve the index structures of the one-wave lite solver (one- and two-wave launches of up to 2048
+// instances use it; without the room lite_build declines and the general solver runs).
 static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int64_t rows_raw, int64_t p, int64_t nnzM,
-                                         int64_t nt = 256, bool pm1 = false) {
+                                         int64_t nt = 256, bool pm1 = false, bool lite_room = true) {
   // bottom: persistent through the solve
   uint64_t persist = align8u(d) + align8u(4 * (d + 1)) + align8u(4 * (p + 1)) + align8u(p)       // usign, cptr, mptr, vkind
                      + 2 * align8u(2 * nnzM) + (pm1 ? 0 : 2 * align8u(4 * nnzM));               // mcol, cvar (+ mval, cvalc)
@@ -534,23 +536,23 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
   uint64_t solve = 3 * align8u(8 * d) + align8u(4 * d)                                           // res, tvec/q, rc, wold
                    + 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p)  // theta..step, told, H, act, long rows
                    + 8 + 2 * 8 * 33;                                                              // dummy slots of the lite form
-  if (pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)nnzM);  // lite index structures
+  if (lite_room && pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)nnzM);
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
 }
 
-static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes) {
+static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes, bool lite_room = true) {
   // structured cones: <= d unit entries + a few sparse rows; dense tiny cones: m*d
   int64_t cap = 4 * (m_max + d) + 256;
   if (cap > m_max * d) cap = m_max * d;
   if (cap < 64) cap = 64;
   // sized for structured cones (+-1 entries, <= 32 reduced rows, <= 64 general rows); a cone that
   // needs more reports ST_TOO_LARGE and the caller retries with the full 160 KiB arena
-  uint64_t need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10, 256, true);
+  uint64_t need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10, 256, true, lite_room);
   while (need > kMaxLds && cap > 256) {
     cap = cap * 3 / 4;
-    need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10, 256, true);
+    need = arena_bytes_dense(m_max, d, cap, 64, 32, cap * 6 / 10, 256, true, lite_room);
   }
   if (need > kMaxLds) need = kMaxLds;
   if (nnz_cap) *nnz_cap = (int32_t)cap;
@@ -558,13 +560,13 @@ static inline int32_t default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap,
   return 0;
 }
 
-static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& lds) {
+static inline bool resolve_limits(int64_t m, int64_t d, int32_t& cap, int32_t& lds, bool lite_room = true) {
   int32_t dcap = 0, dlds = 0;
-  default_limits(m, d, &dcap, &dlds);
+  default_limits(m, d, &dcap, &dlds, lite_room);
   if (cap <= 0) cap = dcap;
   if (lds <= 0) {
     // honour a caller-supplied nnz_cap when deriving the arena size
-    uint64_t need = arena_bytes_dense(m, d, cap, 64, 32, (int64_t)cap * 6 / 10, 256, true);
+    uint64_t need = arena_bytes_dense(m, d, cap, 64, 32, (int64_t)cap * 6 / 10, 256, true, lite_room);
     lds = (int32_t)(need > kMaxLds ? kMaxLds : need);
   }
   return lds > 0 && (uint32_t)lds <= kMaxLds && cap > 0;
@@ -593,7 +595,9 @@ static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int
          align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096 + 256;  // + staging buffers (at most 4096 entries each)
 }
 
-static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false) {
+// lite_room: reserve the index structures of the one-wave lite solver (only launches of up to 2048 instances use it)
+static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false,
+                                       bool lite_room = true) {
   uint64_t s = 0;
   int64_t p = max_rows;
   s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
@@ -601,7 +605,7 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += 2 * (align8u(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : align8u(4 * (int64_t)max_nnz)));  // CSR + CSC (+ values)
   s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
   s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256 + 8 + 2 * 8 * 33;
-  if (all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
+  if (lite_room && all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
     const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)max_nnz);
     if (with_lite <= kMaxLds) s = with_lite;
   }

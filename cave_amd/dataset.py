@@ -192,6 +192,8 @@ class ConeStore:
         # <= 1024 non-zeros, d <= 256; columns with more than 8 entries fall back inside the kernel)
         self.lite = self.all_pm1 and self.max_rows <= 32 and self.max_nnz <= 1024 and d <= 256
         self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, int(self.all_pm1)))
+        # large batches (> 2048 instances) run the general solver: no room reserved for the lite structures
+        self.lds_bytes_big = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, 2 if self.all_pm1 else 0))
         # cones beyond the LDS-resident solver (more than 64 reduced rows or too many non-zeros) run on the
         # large-cone path, which reads the store in place and keeps the Newton systems as bands
         self.large = self.lds_bytes <= 0 or self.max_rows > 64
@@ -226,7 +228,7 @@ class ConeStore:
         puts more instances in flight and wins on throughput (measured crossover between 1024 and 2048)."""
         if self.waves in (1, 2, 4, 8):
             return self.waves if (self.waves != 4 or self.fits4) else 2
-        if self.lite:
+        if self.lite and B <= 2048:
             return 1  # small +-1 cones: the one-wave kernels carry the lite solver (cone_core.h)
         if self.lds_bytes > 80 * 1024:
             return 8  # one workgroup per CU whatever the shape: four waves with the wide register budget (64 rows)
@@ -300,7 +302,7 @@ class ConeStore:
             else:
                 rc = lib.cave_hip_cone_packed(
                     C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                    int(max_iter), self.lds_bytes, self._waves_for(B),
+                    int(max_iter), self.lds_bytes if B <= 2048 else self.lds_bytes_big, self._waves_for(B),
                     _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())

@@ -262,7 +262,7 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             _lib.check(rc, "cave_hip_cone_packed (slot mode)")
 
         # small cones: the split form, once a checked batch of this shape has fitted it (or when this call is checked)
-        if auto and waves == 0 and 0 < m and d <= SPLIT_MAX_D and (m, d) not in _tier:
+        if auto and waves == 0 and 0 < m and d <= SPLIT_MAX_D and B <= 2048 and (m, d) not in _tier:
             ok = _split_ok.get((m, d))
             if ok is True or (ok is None and check):
                 launch_split()

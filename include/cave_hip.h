@@ -175,7 +175,10 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
 
 /* LDS bytes cave_hip_cone_packed needs for the largest instance of a store
  * (max_rows / max_nnz over instances, from the pass-1 counts).  all_pm1 != 0: every instance has
- * flags bit0 set, so no value arrays are staged (smaller arena -> more workgroups per CU). */
+ * flags bit0 set, so no value arrays are staged (smaller arena -> more workgroups per CU).  all_pm1 == 1 also
+ * reserves room for the index structures of the one-wave solver for small cones (d <= 256, <= 32 rows), which
+ * launches of up to 2048 instances use; all_pm1 == 2: +-1 cones without that room (large batches: more
+ * workgroups per CU matter more there). */
 int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1);
 
 /* ------------------------------------------------------------------ large-cone path
