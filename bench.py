@@ -48,6 +48,9 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip packed-path / train-step side measurements")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the side measurements at the instance sizes of BASELINE configs 3-5")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="overlap the pack stage of step i+1 (side stream) with the solve stage of step i "
+                         "(measured: 182 vs 192 us/step -- the two kernels slow each other down; off by default)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / JSON-relay check without a GPU (gloo, no kernels; CPU tests)")
     return ap.parse_args(argv)
@@ -255,9 +258,28 @@ def main(argv=None):
     outs = ("proj", "rnorm") if mode == _lib.MODE_PROJECT else ("loss", "grad")
     red = torch.zeros(2, device=dev)
 
+    from cave_amd.qpsolver import PreparedCones, cone_op_prepared, prepare_dense, stream_mark
+
+    # Optional software pipeline across steps (--pipeline): the pack stage of step i+1 (stream the dense cones of the
+    # NEXT batch, build its reduced cones: depends on the cones only, which a DataLoader has collated ahead of the
+    # predictor) runs on a side stream while step i's solve kernel runs; every timed step still launches exactly one
+    # pack and one solve.  Default: the two stages back to back on one stream.
+    state = {"prep": None}
+
     def step(i):
         _, _, c, p = batches[i % R]
-        o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
+        if args.pipeline:
+            prep = state["prep"] if state["prep"] is not None else prepare_dense(c)
+            mark = stream_mark(dev)
+            if isinstance(prep, PreparedCones):
+                o = cone_op_prepared(prep, p, mode, -1.0, 0.2, check=False, outputs=outs)
+            else:
+                o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
+            # enqueued AFTER the solve: the solve's workgroups take their residency first, the pack of the next
+            # batch fills what is left of each CU (one 4-wave workgroup next to four one-wave solve workgroups)
+            state["prep"] = prepare_dense(batches[(i + 1) % R][2], ready=mark)
+        else:
+            o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
         if world > 1 and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
             red[0] = o["loss"].sum()
             red[1] = float(B)
@@ -335,6 +357,11 @@ def main(argv=None):
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
+            "pipeline": {"across_steps": bool(args.pipeline and split),
+                         "unpipelined_ms_per_step": kern_ms,
+                         "note": "--pipeline overlaps the pack stage of step i+1 with the solve stage of step i on a side "
+                                 "stream (cave_amd.qpsolver.prepare_dense); measured gain ~5 %: co-resident, the two "
+                                 "kernels slow each other down (solve 130 -> 175 us, pack 60 -> 147 us)."},
         }
         if not args.no_extras:
             res.update(extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs))

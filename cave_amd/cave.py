@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from .abcmodule import EPO, optModule, sense_sign
 from .dataset import PackedBatch
-from .qpsolver import cone_op_dense
+from .qpsolver import PreparedCones, cone_op_dense, cone_op_prepared, prepare_dense
 
 __all__ = ["exactConeAlignedCosine", "innerConeAlignedCosine", "abstractConeAlignedCosine", "EPO", "flush_checks"]
 
@@ -98,6 +98,9 @@ class _ConeLossFunction(torch.autograd.Function):
         if isinstance(tight_ctrs, PackedBatch):  # device-resident cones, ids only (cave_amd/dataset.py)
             o = tight_ctrs.store.cone_op(tight_ctrs.ids, pred_cost, mode, sign, inner_ratio,
                                          outputs=("loss", "grad"), **_packed_kwargs(kwargs))
+        elif isinstance(tight_ctrs, PreparedCones):  # dense batch whose pack stage ran ahead (qpsolver.prepare_dense)
+            o = cone_op_prepared(tight_ctrs, pred_cost, mode, sign, inner_ratio, outputs=("loss", "grad"),
+                                 **_packed_kwargs(kwargs))
         else:
             if lazy and not _dense_shape_settled(tight_ctrs):
                 kwargs = dict(kwargs, check=True)  # first call for this shape: strict, so the launch tier can settle
@@ -141,6 +144,14 @@ class abstractConeAlignedCosine(optModule):
 
     def _inner_ratio(self) -> float:
         return 0.0
+
+    @staticmethod
+    def prepare(tight_ctrs: torch.Tensor, ready=None):
+        """Start the prediction-independent half of the forward pass (streaming the dense cones and building the
+        reduced cones) for a batch that will be used in a later call: `nxt = loss_fn.prepare(next_bctr)` while the
+        current step runs, then `loss_fn(cp, nxt)`.  Returns an object to pass in place of `tight_ctrs`
+        (the tensor itself when the shape does not qualify).  `ready`: see qpsolver.prepare_dense / stream_mark."""
+        return prepare_dense(tight_ctrs, ready)
 
     def _solver_kwargs_for_call(self) -> dict:
         return self.solver_kwargs

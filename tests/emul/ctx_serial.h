@@ -34,6 +34,7 @@ struct SerialCtx {
   uint32_t reduce_add_u32(uint32_t v) const { return v; }
   void atomic_add_u32(uint32_t* p, uint32_t v) const { *p += v; }
   uint32_t atomic_inc_ret_u32(uint32_t* p) const { return (*p)++; }
+  void atomic_or_u32(uint32_t* p, uint32_t v) const { *p |= v; }
   void atomic_add_f64(double* p, double v) const { *p += v; }
   void atomic_add_f64_lds(double* p, double v) const { *p += v; }
   uint32_t exclusive_scan_u32(uint32_t* a, int n) const {

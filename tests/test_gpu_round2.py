@@ -297,3 +297,54 @@ def test_training_harness_on_tsp_with_warm_start():
     assert hist[-1][2] < hist[0][2] and hist[-1][1] < hist[1][1], hist
     log = train_sp_cave.main.iters_log
     assert all(m <= 3.0 for m, _ in log[1:]), log
+
+
+def test_prepared_form_pipelines_pack_and_solve(golden):
+    """loss_fn.prepare(next_bctr): the prediction-independent pack stage on a side stream; the later loss call only
+    launches the solve.  Same numbers as the ordinary call, also through the modules, also after many reuses of the
+    three slot stores, and a batch beyond the slot capacity falls back."""
+    import torch
+
+    from cave_amd import qpsolver, synth
+    from cave_amd.cave import EPO, innerConeAlignedCosine
+    from cave_amd.qpsolver import PreparedCones, cone_op_dense, cone_op_prepared, prepare_dense
+
+    ctrs, costs, _ = synth.tsp_batch(20, 64, seed=13)
+    key = (ctrs.shape[1], ctrs.shape[2])
+    qpsolver.forget_shape(*key)
+    rng = np.random.default_rng(3)
+    batches = [(torch.tensor(ctrs[rng.permutation(64)[:48]], device="cuda"),
+                torch.tensor(costs[:48] + rng.normal(0, 0.1, (48, costs.shape[1])).astype(np.float32), device="cuda"))
+               for _ in range(7)]
+    want = [cone_op_dense(c, p, MODE_INNER, -1.0, 0.2, outputs=ALL) for c, p in batches]
+    prep = prepare_dense(batches[0][0])
+    assert isinstance(prep, PreparedCones)
+    for i, (c, p) in enumerate(batches):
+        nxt = prepare_dense(batches[(i + 1) % len(batches)][0])   # next batch's pack overlaps this batch's solve
+        got = cone_op_prepared(prep, p, MODE_INNER, -1.0, 0.2, outputs=ALL)
+        for k in ALL:
+            assert torch.equal(got[k], want[i][k]), (i, k)
+        prep = nxt
+
+    class M:
+        modelSense = EPO.MINIMIZE
+
+    mod = innerConeAlignedCosine(M(), solver="hip", seed=0)
+    c, p = batches[2]
+    pr = p.clone().requires_grad_(True)
+    l1 = mod(pr, mod.prepare(c))
+    l1.backward()
+    pr2 = p.clone().requires_grad_(True)
+    l2 = mod(pr2, c)
+    l2.backward()
+    assert torch.equal(l1.detach(), l2.detach()) and torch.equal(pr.grad, pr2.grad)
+    # beyond the slots: a dense row block makes instance 3 a non +-1 cone with 40 general rows
+    big = ctrs[:8].copy()
+    big[3, :40, :30] = rng.standard_normal((40, 30)).astype(np.float32)
+    qpsolver.forget_shape(*key)
+    bt, pt = torch.tensor(big, device="cuda"), torch.tensor(costs[:8], device="cuda")
+    got = cone_op_prepared(prepare_dense(bt), pt, MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    ref = cone_op_dense(bt, pt, MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    assert bool((got["status"] == 0).all()) and torch.equal(got["proj"], ref["proj"])
+    assert prepare_dense(bt) is bt  # the shape is now known not to fit: prepare declines
+    qpsolver.forget_shape(*key)

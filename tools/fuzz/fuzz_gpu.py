@@ -23,13 +23,26 @@ while time.time() - t0 < T:
     if time.time() - last_report > 60:  # the GPU box kills a run that is silent for 7 minutes
         last_report = time.time()
         print(f"... {int(time.time() - t0)} s, {n} batches/instances so far, {bad} mismatches", flush=True)
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     if kind == 0:
         nn = int(rng.integers(4, 21)); B = 48
         A, y, _ = synth.tsp_batch(nn, B, seed=int(rng.integers(1 << 30)))
     elif kind == 1:
         h, w = int(rng.integers(2, 7)), int(rng.integers(2, 7)); B = 48
         A, y, _ = synth.sp_batch(h, w, B, seed=int(rng.integers(1 << 30)))
+    elif kind == 5:
+        # adversarial +-1 cones for the one-wave lite solver: sparse rows with entries in {-1, 0, 1}, exact
+        # duplicates, negated copies (equality pairs), unit rows, rank deficiency, predictions on faces
+        d, m, B = int(rng.integers(2, 40)), int(rng.integers(1, 36)), 32
+        A = (rng.integers(-1, 2, (B, m, d)) * (rng.random((B, m, d)) < rng.choice([0.15, 0.4, 0.8]))).astype(np.float32)
+        for b in range(B):
+            for _ in range(int(rng.integers(0, 4))):
+                i, j = rng.integers(0, m, 2)
+                A[b, i] = A[b, j] * rng.choice([1.0, -1.0])
+        y = rng.standard_normal((B, d)).astype(np.float32)
+        if rng.random() < 0.3:  # prediction inside / on the cone
+            lam = np.maximum(rng.standard_normal((B, m)), 0).astype(np.float32)
+            y = np.einsum("bm,bmd->bd", lam, A).astype(np.float32)
     else:
         d, m, B = int(rng.integers(1, 24)), int(rng.integers(0, 40)), 32
         A = rng.standard_normal((B, m, d)).astype(np.float32)
@@ -75,7 +88,7 @@ while time.time() - t0 < T:
             bad += 1
             if bad <= 5: print("MISMATCH kind", kind, A.shape, "waves", waves, "mode", mode, "err", e)
 
-    if kind in (0, 1):
+    if kind in (0, 1, 5):
         st = ConeStore.from_dense(At)
         ids = torch.randperm(B, device="cuda")
         for waves in (1, 2):
