@@ -461,21 +461,18 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
 //                      P(last entry of i) - P(last entry of i - 1): two LDS reads per row, no segment logic.
 struct LiteCone {
   const uint32_t* ell;    // [4 * d]            (16-byte aligned)
-  const uint32_t* csr16;  // 32 * chn8 words    (16-byte aligned)
-  double* pendv;          // [1 + 32 + 1] global prefix at the end of the k-th non-empty row (slot k + 1; slot 0 = 0;
-                          //              the last slot takes the writes of positions that end no row)
-  const uint32_t* lend;   // [64] per lane: bit c = entry c of the lane's run ends a row | first such row's slot << 16
-  const uint16_t* pend;   // [p + 1]  pend[i + 1]: slot of the last non-empty row <= i (pend[0] = 0)
+  const uint32_t* csr16;  // [4 * 64 * chn8 / 8 ... ] = 32 * chn8 words (16-byte aligned)
+  double* pfx;            // [64 * chn8 + 1]    prefix sums, slot c * 64 + lane; the last slot stays 0
+  const uint16_t* pend;   // [p + 1]            pend[i + 1]: slot of the last entry of row i (pend[0]: the zero slot)
   int chn8;               // CSR entries per lane: 8 or 16
   int cmax;               // largest column count
 };
 static constexpr int kLiteMaxRows = 32, kLiteMaxD = 256, kLiteMaxCol = 8, kLiteMaxChunk = 16;
 static constexpr uint32_t kLiteDummyRow = 32;
-static constexpr uint32_t kLiteDumpSlot = 33;
 
 CAVE_HOSTDEV uint32_t lite_lds_bytes(int d, uint32_t nnz) {
   const uint32_t chn8 = nnz <= 512u ? 8u : 16u;
-  return 16u * (uint32_t)d + 128u * chn8 + 8u * 34u + 4u * 64u + 2u * 34u + 4u * 64u + 64u;
+  return 16u * (uint32_t)d + 128u * chn8 + 8u * (64u * chn8 + 1u) + 2u * 34u + 64u;
 }
 
 // Build the lite structures (all threads of the context).  Returns false when the cone does not qualify or the
@@ -488,13 +485,11 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
   const uint32_t nnz = v.mptr[p];
   if (nnz == 0u || nnz > 64u * (uint32_t)kLiteMaxChunk) return false;
   const uint32_t chn8 = nnz <= 512u ? 8u : 16u;
-  uint32_t* ell = ar.try_get<uint32_t, 16u>(4u * (uint32_t)d);  // read 16 bytes at a time
+  uint32_t* ell = ar.try_get<uint32_t, 16u>(4u * (uint32_t)d);
   uint32_t* csr16 = ell ? ar.try_get<uint32_t, 16u>(32u * chn8) : nullptr;
-  double* pendv = csr16 ? ar.try_get<double>(34u) : nullptr;
-  uint32_t* lend = pendv ? ar.try_get<uint32_t>(64u) : nullptr;
-  uint16_t* pend = lend ? ar.try_get<uint16_t>(34u) : nullptr;
-  uint32_t* scr = pend ? ar.try_get<uint32_t>(64u) : nullptr;  // scan scratch (build only)
-  if (!scr) return false;
+  double* pfx = csr16 ? ar.try_get<double>(64u * chn8 + 1u) : nullptr;
+  uint16_t* pend = pfx ? ar.try_get<uint16_t>(34u) : nullptr;
+  if (!pend) return false;
   // columns -> ELL rows of 8 (unused slots: the dummy row)
   uint32_t over = 0;
   double cm = 0.0;
@@ -519,34 +514,22 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
     const uint32_t x = v.mcol[e < nnz ? e : 0u];
     c16[idx] = (uint16_t)(e < nnz ? (x ^ 0x8000u) : (uint32_t)d);
   }
-  // where each row ends: per lane a mask of run positions that end a (non-empty) row and the slot of the first one
-  for (int l = c.tid(); l < 64; l += NT) lend[l] = 0u;
-  for (int i = c.tid(); i < 34; i += NT) pendv[i] = 0.0;
-  c.sync();
-  for (int i = c.tid(); i < p; i += NT) {
-    const uint32_t lo = v.mptr[i], hi = v.mptr[i + 1];
-    if (hi > lo) {
+  // where the prefix of each row's last entry will be found
+  for (int i = c.tid(); i <= p; i += NT) {
+    const uint32_t hi = v.mptr[i];  // one past the last entry of row i - 1
+    uint32_t slot = 64u * chn8;     // the zero slot: nothing before the first row
+    if (i > 0 && hi > 0u) {
       const uint32_t e = hi - 1u;
-      c.atomic_or_u32(&lend[e / chn8], 1u << (e % chn8));
+      slot = (e % chn8) * 64u + e / chn8;
     }
+    pend[i] = (uint16_t)slot;
   }
-  // slots of the non-empty rows, in order: pend[i + 1] = number of non-empty rows <= i
-  for (int i = c.tid(); i <= p; i += NT) scr[i] = (i < p && v.mptr[i + 1] > v.mptr[i]) ? 1u : 0u;
-  c.sync();
-  c.exclusive_scan_u32(scr, p + 1);
-  for (int i = c.tid(); i <= p; i += NT) pend[i] = (uint16_t)scr[i];
-  c.sync();
-  // first slot of every lane = non-empty rows ending before its run
-  for (int l = c.tid(); l < 64; l += NT) scr[l] = (uint32_t)__builtin_popcount(lend[l] & 0xffffu);
-  c.sync();
-  c.exclusive_scan_u32(scr, 64);
-  for (int l = c.tid(); l < 64; l += NT) lend[l] = (lend[l] & 0xffffu) | (scr[l] << 16);
+  if (c.tid() == 0) pfx[64u * chn8] = 0.0;
   over = c.reduce_add_u32(over);
   L.cmax = (int)c.reduce_max(cm);
   c.sync();
   if (over) return false;
-  c.sync();
-  L.ell = ell; L.csr16 = csr16; L.pendv = pendv; L.lend = lend; L.pend = pend; L.chn8 = (int)chn8;
+  L.ell = ell; L.csr16 = csr16; L.pfx = pfx; L.pend = pend; L.chn8 = (int)chn8;
   return true;
 }
 
@@ -609,22 +592,13 @@ __device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, co
     }
   }
   const double base = wave_inclusive_scan_f64(run) - run;  // sum of the lanes before this one
-  // publish the global prefix at every row end of this lane's run (positions that end no row write the dump slot)
-  const uint32_t le = L.lend[lane];
-  uint32_t slot = 1u + (le >> 16);
 #pragma unroll
-  for (int cc = 0; cc < kLiteMaxChunk; ++cc) {
-    if (cc < L.chn8) {
-      const bool ends = (le >> cc) & 1u;
-      L.pendv[ends ? slot : kLiteDumpSlot] = base + pre[cc];
-      slot += ends ? 1u : 0u;
-    }
-  }
+  for (int cc = 0; cc < kLiteMaxChunk; ++cc)
+    if (cc < L.chn8) L.pfx[cc * 64 + lane] = base + pre[cc];
   c.sync();
-  if (lane < p) g[lane] = L.pendv[L.pend[lane + 1]] - L.pendv[L.pend[lane]];
+  if (lane < p) g[lane] = L.pfx[L.pend[lane + 1]] - L.pfx[L.pend[lane]];
   c.sync();
 }
-
 // H += (w_k - w_k_old) m_k m_k^T for the coordinates whose smoothed weight changed (see solve_cone_impl), lite
 // form: four coordinates per lane, all of their operands loaded before the first weight is computed; each
 // column comes in one 16-byte read and all lanes walk its (e1, e2 <= e1) pairs together, stopping at the longest
