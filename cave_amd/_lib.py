@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill", "cave_hip_cone_packed",
     "cave_hip_packed_lds_bytes",
     "cave_hip_large_slice_bytes", "cave_hip_packed_large_slice_bytes", "cave_hip_cone_dense_large",
-    "cave_hip_pack_large", "cave_hip_cone_packed_large",
+    "cave_hip_pack_large", "cave_hip_cone_packed_large", "cave_hip_packed_large_lds_bytes",
 )
 
 
@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
     lib.cave_hip_large_slice_bytes.restype = i64
     lib.cave_hip_packed_large_slice_bytes.argtypes = [i64, i64, i64]
     lib.cave_hip_packed_large_slice_bytes.restype = i64
+    lib.cave_hip_packed_large_lds_bytes.argtypes = [i32, i32]
+    lib.cave_hip_packed_large_lds_bytes.restype = i32
     lib.cave_hip_cone_dense_large.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i64, i32, vp, i64, i32,
                                               vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cave_hip_pack_large.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, vp, vp, C.POINTER(Store), i64, vp, vp]

@@ -12,6 +12,7 @@
 // XCD-aware remap is needed (nothing is shared through L2).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/cave_hip.h"
@@ -82,6 +83,7 @@ struct LargeWs {
   uint64_t slice;  // bytes per workgroup (< 4 GiB)
 };
 using CtxL = BlockCtx<4, true>;
+using CtxL2 = BlockCtx<2, true>;
 
 __global__ __launch_bounds__(CtxL::NT, 2) void cone_dense_large_kernel(DenseParams P, LargeWs W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,9 +107,13 @@ __global__ __launch_bounds__(CtxL::NT, 2) void cone_pack_large_kernel(PackParams
   }
 }
 
-__global__ __launch_bounds__(CtxL::NT, 2) void cone_packed_large_kernel(PackedParams P, LargeWs W) {
+// (MINW = waves per SIMD the register budget is set for: 2 -> 256 VGPRs.  C = CtxL: 4 waves, two workgroups per CU;
+//  CtxL2 / Ctx1: 2 / 1 waves, four and more workgroups per CU where the LDS allows -- for batches that fill the
+//  chip several times over with narrow-band cones, whose elimination runs on one wave anyway: cone_band.h)
+template <class C, int MINB>
+__global__ __launch_bounds__(C::NT, MINB) void cone_packed_large_kernel(PackedParams P, LargeWs W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  CtxL c;
+  C c;
   c.init(smem);
   unsigned char* ws = W.base + (uint64_t)blockIdx.x * W.slice;
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(CtxL::NT, 2) void cone_packed_large_kernel(PackedPa
     for (int i = 0; i < 16; ++i) c.st[i] = 0;
     unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    run_packed_large_instance<CtxL>(c, smem, P, b, ws, (uint32_t)W.slice);
+    run_packed_large_instance<C>(c, smem, P, b, ws, (uint32_t)W.slice);
 #ifdef CAVE_STAMPS
     c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
     c.st[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
@@ -301,6 +307,11 @@ int64_t cave_hip_packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t b
   return (int64_t)packed_large_slice_bytes(d, max_rows, band_entries);
 }
 
+int32_t cave_hip_packed_large_lds_bytes(int32_t max_rows, int32_t max_bw) {
+  if (max_rows < 0 || max_bw < 0) return CAVE_E_INVALID;
+  return (int32_t)packed_large_lds_bytes(max_rows, max_bw);
+}
+
 static int32_t check_large(const char* who, const void* workspace, int64_t slice_bytes, int32_t n_slots, int32_t& lds_bytes) {
   if (!workspace || slice_bytes < 1024 || slice_bytes >= ((int64_t)1 << 32) || (slice_bytes & 7) || n_slots <= 0 ||
       ((uintptr_t)workspace & 15u)) {
@@ -315,12 +326,13 @@ static int32_t check_large(const char* who, const void* workspace, int64_t slice
   return CAVE_OK;
 }
 
-#define CAVE_LAUNCH_LARGE(KERNEL, B, SLOTS, LDS, STREAM, PARAMS, WS, WHAT)                                      \
+#define CAVE_LAUNCH_LARGE(KERNEL, B, SLOTS, LDS, STREAM, PARAMS, WS, WHAT) CAVE_LAUNCH_LARGE_NT(KERNEL, CtxL::NT, B, SLOTS, LDS, STREAM, PARAMS, WS, WHAT)
+#define CAVE_LAUNCH_LARGE_NT(KERNEL, NT_, B, SLOTS, LDS, STREAM, PARAMS, WS, WHAT)                             \
   do {                                                                                                         \
     hipError_t e_ = ensure_lds(KERNEL, (uint32_t)(LDS));                                                       \
     if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "hipFuncSetAttribute(" WHAT ")", e_);                     \
     unsigned grid_ = (unsigned)((B) < (int64_t)(SLOTS) ? (B) : (int64_t)(SLOTS));                              \
-    hipLaunchKernelGGL(KERNEL, dim3(grid_), dim3(CtxL::NT), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS, WS); \
+    hipLaunchKernelGGL(KERNEL, dim3(grid_), dim3(NT_), (size_t)(LDS), (hipStream_t)(STREAM), PARAMS, WS); \
     e_ = hipGetLastError();                                                                                    \
     if (e_ != hipSuccess) return fail(CAVE_E_LAUNCH, "launch " WHAT, e_);                                      \
   } while (0)
@@ -389,7 +401,18 @@ int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* 
   P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   LargeWs W{(unsigned char*)workspace, (uint64_t)slice_bytes};
-  CAVE_LAUNCH_LARGE(cone_packed_large_kernel, B, n_slots, lds_bytes, stream, P, W, "cone_packed_large_kernel");
+  // workgroup shape: 4 waves (two workgroups per CU) unless the batch needs more than two workgroups per CU and
+  // four fit the LDS; then 2 waves.  CAVE_LARGE_WAVES=1|2|4 overrides (diagnostic).
+  const int64_t grid = B < n_slots ? B : n_slots;
+  int waves = (grid > 2 * 256 && (int64_t)lds_bytes * 4 <= (int64_t)kMaxLds) ? 2 : 4;
+  if (const char* e = getenv("CAVE_LARGE_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) waves = v; }
+  if (waves == 1) {
+    CAVE_LAUNCH_LARGE_NT((cone_packed_large_kernel<Ctx1, 2>), Ctx1::NT, B, n_slots, lds_bytes, stream, P, W, "cone_packed_large_kernel<1>");
+  } else if (waves == 2) {
+    CAVE_LAUNCH_LARGE_NT((cone_packed_large_kernel<CtxL2, 2>), CtxL2::NT, B, n_slots, lds_bytes, stream, P, W, "cone_packed_large_kernel<2>");
+  } else {
+    CAVE_LAUNCH_LARGE_NT((cone_packed_large_kernel<CtxL, 2>), CtxL::NT, B, n_slots, lds_bytes, stream, P, W, "cone_packed_large_kernel<4>");
+  }
   return CAVE_OK;
 }
 

@@ -369,4 +369,280 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   CAVE_ACC(12);
 }
 
+// ---- sizing of the one-wave form below (shared with the host code: cone_instance.h, cave_hip.hip)
+constexpr int kBandWaveDuos = 5;   // duos per lane
+constexpr int kBandWaveRegs = 20;  // prefetch registers per lane: one staged chunk = bw + 1 rows
+
+CAVE_HOSTDEV int band_wave_duos(int bw) {
+  int nd = 0;
+  for (int len = 1; len <= bw; ++len) nd += (len + 1) / 2;
+  return nd;
+}
+CAVE_HOSTDEV bool band_wave_fits(int bw, int p) {
+  if (bw < 1 || p <= bw + 1) return false;
+  if ((bw + 1) * (bw + 1) > 64 * kBandWaveRegs) return false;
+  return band_wave_duos(bw) <= 64 * kBandWaveDuos;
+}
+// window row stride: one zero pad column (the second operand of a duo that has no second entry reads it), odd so
+// that consecutive rows start on different banks
+CAVE_HOSTDEV int band_wave_stride(int bw) { return ((bw + 2) & 1) ? bw + 2 : bw + 3; }
+
+// staging entries: two chunks of bw + 1 raw rows on the way down, a 64-row ring of factor rows on the way back
+CAVE_HOSTDEV uint32_t band_wave_staging(int bw) {
+  const uint32_t ld = (uint32_t)bw + 1u, a = 2u * ld * ld, b = 64u * ld + 1u;
+  return a > b ? a : b;
+}
+
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------ narrow bands on ONE wave
+// What the team form above costs on a 30x30 grid (bw = 30, p = 900; rocprof + the stamp build): every pivot is a
+// workgroup barrier plus ~200 instructions in EACH of the four waves for 465 window updates -- the kernel is
+// bound by instruction issue, not by LDS or HBM, and two resident workgroups per CU only slow each other down.
+// Here ONE wave runs the whole elimination: no barriers (the LDS operations of a wave execute in order), the
+// update triangle is dealt out as "duos" (two adjacent entries of one window row: one ds_read_b64 for the
+// multiplier, two ds_read2_b64 for the pivot-row and target operands, one ds_write2_b64), the reciprocal pivot is
+// v_rcp_f64 + two Newton steps, and all bw + 1 rows a pivot reaches are resident when it is processed, so the
+// steady state has no special cases: rows past the end of the matrix enter as zeros.
+// The back substitution is column oriented: lane (j mod 64) owns the partial sum of row j, every finished x_k is
+// folded into the bw rows above it with one fma per lane, and the loop-carried chain is a v_readlane pair and three
+// fp64 operations instead of a wave reduction per row (~470 -> ~60 cycles per row).
+// Same semantics as solve_spd_band (identity rows, shift, dropped pivots).  Needs win[(bw+1) * stride],
+// stg[2 * (bw+1)^2], z[p], x[p], act[p] in LDS and p > bw + 1.
+__device__ __forceinline__ double rcp_full(double d) {  // 1/d to double accuracy for d > 0
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
+  return inv;
+}
+
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* q) {  // arguments of a real call arrive in VGPRs: make them scalar again
+  const uint64_t v = (uint64_t)q;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (T*)(((uint64_t)hi << 32) | lo);
+}
+
+CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* Hb_v, const int bw_v, const double* rhs_v,
+                                                  const uint8_t* act_v, const int p_v, const double reg_rel, double* win_v,
+                                                  double* fac_v, double* z_v, double* x_v, double* stg_v,
+                                                  unsigned long long* stamps = nullptr) {
+  constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs;
+  const int bw = __builtin_amdgcn_readfirstlane(bw_v), p = __builtin_amdgcn_readfirstlane(p_v);
+  const double* Hb_ = uniform_ptr(Hb_v);
+  const double* rhs = uniform_ptr(rhs_v);
+  const uint8_t* act_ = uniform_ptr(act_v);
+  double* win_ = uniform_ptr(win_v);
+  double* fac_ = uniform_ptr(fac_v);
+  double* z_ = uniform_ptr(z_v);
+  double* x_ = uniform_ptr(x_v);
+  double* stg_ = uniform_ptr(stg_v);
+#ifdef CAVE_STAMPS
+  struct { unsigned long long* st; } c{stamps};
+#endif
+  CAVE_T0();
+  const int ld = bw + 1, wl = band_wave_stride(bw), csz = ld * ld, wsz = ld * wl;
+  auto Hb = space_cast<1>(Hb_);
+  auto fac = space_cast<1>(fac_);
+  auto act = space_cast<3>(act_);
+  auto win = space_cast<3>(win_);
+  auto z = space_cast<3>(z_);
+  auto x = space_cast<3>(x_);
+  auto stg = space_cast<3>(stg_);
+  double md = 0.0;
+  uint32_t nfix = 0;
+  for (int i = lane; i < p; i += 64) {
+    if (!act[i]) md = fmax(md, Hb[i * ld]);
+    else nfix++;
+  }
+  md = wave_max_f64(md);
+  nfix = wave_sum_u32(nfix);
+  const double reg = reg_rel * md;
+  for (int i = lane; i < p; i += 64) {
+    double zi = rhs[i];
+    if (nfix != 0u && !act[i]) {
+      const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
+      for (int j = j0; j <= j1; ++j)
+        if (act[j]) zi -= ((i >= j) ? Hb[j * ld + (i - j)] : Hb[i * ld + (j - i)]) * rhs[j];
+    }
+    z[i] = zi;
+  }
+  double regs[RMAX];
+  auto fetch = [&](decltype(Hb) src, int e0, int eend) {  // unconditional loads from clamped indices
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      int e = e0 + lane + j * 64;
+      e = e < eend ? e : eend - 1;
+      regs[j] = src[e > 0 ? e : 0];
+    }
+  };
+  auto park = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      const int idx = lane + j * 64;
+      if (idx < csz) stg[b * csz + idx] = regs[j];
+    }
+  };
+  // rows 0 .. bw of the band as the elimination sees them, pad columns zero
+  for (int idx = lane; idx < wsz; idx += 64) {
+    const int r = idx / wl, t = idx - r * wl;
+    win[idx] = (t <= bw) ? band_row_entry(Hb, ld, act, p, reg, r, t) : 0.0;
+  }
+  // chunk c = raw rows ld + c*ld .. of H; chunk c is consumed from buffer c & 1 while pivots c*ld .. run
+  fetch(Hb, ld * ld, p * ld);
+  park(0);
+  fetch(Hb, 2 * ld * ld, p * ld);
+  // this lane's duos: duo q in row-major order over rows s = 1 .. bw (entries t = s, s+2, ...), q = lane + 64 u
+  // (a lane without a duo in the last round repeats duo q mod nd: two lanes then store the same bits to the same
+  //  address, which needs no predicate -- a predicated store drags its loads into the branch, one more LDS round trip)
+  int ua[U], ub[U], ur[U];
+  const int nd = band_wave_duos(bw);
+  {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int q = lane + 64 * u, s = 1;
+      q = q < nd ? q : q % nd;
+      while (q >= (bw - s + 2) / 2) { q -= (bw - s + 2) / 2; ++s; }
+      const int t = s + 2 * q;
+      ua[u] = s;
+      ub[u] = t;                    // t + 1 = bw + 1 is the zero pad column
+      ur[u] = s * wl + (t - s);     // target, relative to the pivot row's slot
+    }
+  }
+  const int nu = (nd + 63) / 64;
+  asm volatile("" ::: "memory");
+  CAVE_ACC(10);
+  auto eliminate = [&](auto nu_tag) __attribute__((always_inline)) {
+    constexpr int NU = decltype(nu_tag)::value;
+    int slot_k = 0, cidx = 0;
+    for (int k = 0; k < p; ++k) {
+      const int base_k = slot_k * wl;
+      auto wk = win + base_k;
+      if (slot_k == 0) {  // first row of chunk cidx: chunk cidx+1 (registers) takes the buffer chunk cidx-1 has left
+        park((cidx + 1) & 1);
+        fetch(Hb, (cidx + 3) * csz, p * ld);
+      }
+      // ---- loads
+      const double dk = wk[0];
+      const double zk = z[k];
+      double pa[NU], pb0[NU], pb1[NU], pr0[NU], pr1[NU];
+      int poff[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        int o = base_k + ur[u];
+        o = o >= wsz ? o - wsz : o;
+        poff[u] = o;
+        pa[u] = wk[ua[u]];
+        pb0[u] = wk[ub[u]];
+        pb1[u] = wk[ub[u] + 1];
+        pr0[u] = win[o];
+        pr1[u] = win[o + 1];
+      }
+      const bool zown = lane < bw && k + 1 + lane < p;
+      const double zw = wk[lane < bw ? 1 + lane : 0];
+      const double zz = z[zown ? k + 1 + lane : k];
+      const bool town = lane <= bw;
+      const double rold = wk[town ? lane : 0];
+      const int rI = k + ld;
+      const bool rin = town && rI + lane < p;
+      const double raw = stg[(cidx & 1) * csz + slot_k * ld + (town ? lane : 0)];
+      const bool aI = act[rI < p ? rI : p - 1] != 0, aJ = act[rin ? rI + lane : p - 1] != 0;
+      // ---- compute
+      const bool ok = dk > 1e-300;
+      double inv = rcp_full(ok ? dk : 1.0);
+      inv = ok ? inv : 0.0;
+      // ---- stores
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const double m = pa[u] * inv;
+        win[poff[u]] = fma(-m, pb0[u], pr0[u]);
+        win[poff[u] + 1] = fma(-m, pb1[u], pr1[u]);
+      }
+      if (zown) z[k + 1 + lane] = fma(-zw * inv, zk, zz);
+      if (town) {
+        fac[k * ld + lane] = (lane == 0) ? inv : rold;
+        double rnew = 0.0;
+        if (rin) rnew = (lane == 0) ? (aI ? 1.0 : raw + reg) : ((aI || aJ) ? 0.0 : raw);
+        wk[lane] = rnew;  // row k + bw + 1 takes the slot row k leaves
+      }
+      if (++slot_k == ld) { slot_k = 0; ++cidx; }
+      asm volatile("" ::: "memory");
+    }
+  };
+  switch (nu) {
+    case 1: eliminate(std::integral_constant<int, 1>{}); break;
+    case 2: eliminate(std::integral_constant<int, 2>{}); break;
+    case 3: eliminate(std::integral_constant<int, 3>{}); break;
+    case 4: eliminate(std::integral_constant<int, 4>{}); break;
+    default: eliminate(std::integral_constant<int, 5>{}); break;
+  }
+  // the factor rows go out through this wave's stores and come back through its loads
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  CAVE_ACC(11);
+  // ---- back substitution  x_k = inv_k (z_k - sum_s U[k][k+s] x_{k+s}), column oriented.
+  // Factor rows come back through a 64-row ring in LDS (row r in slot r & 63; one zero entry behind the ring), so lane l
+  // finds every row it owns at l * ld: the entry of column k in its row is at offset s = k - row, and an offset past
+  // the band is redirected to the zero entry.  Rows are fetched CHB at a time (registers: lane = entry,
+  // register = row), a chunk ahead, and parked once the rows that used their slots are done.
+  constexpr int CHB = RMAX;
+  const int rs = ld, zero_at = 64 * ld;
+  auto ring = stg;
+  ring[zero_at] = 0.0;
+  const int tl = lane < ld ? lane : bw;
+  auto fetch_b = [&](int chi) {  // rows chi, chi-1, .. of the factor
+#pragma unroll
+    for (int j = 0; j < CHB; ++j) {
+      const int r = chi - j > 0 ? chi - j : 0;
+      regs[j] = fac[r * ld + tl];
+    }
+  };
+  auto park_b = [&](int chi) {
+    if (lane < ld) {
+#pragma unroll
+      for (int j = 0; j < CHB; ++j)
+        if (chi - j >= 0) ring[((chi - j) & 63) * rs + lane] = regs[j];
+    }
+  };
+  int chi_next = p - 1;  // top row of the chunk in flight
+  fetch_b(chi_next);
+  while (chi_next >= 0 && chi_next + bw + 1 >= p - 1) {
+    park_b(chi_next);
+    chi_next -= CHB;
+    if (chi_next >= 0) fetch_b(chi_next);
+  }
+  asm volatile("" ::: "memory");
+  {
+    double acc = 0.0;  // partial sum of the row this lane owns (row = lane mod 64)
+    const int rowbase = lane * rs;
+    auto col_off = [&](int k) -> int {  // offset of column k in this lane's row, clamped onto the zero entry
+      const int sft = 1 + ((k - 1 - lane) & 63);
+      return sft < ld ? rowbase + sft : zero_at;
+    };
+    double f0n = ring[((p - 1) & 63) * rs], zn = z[p - 1], fn = ring[col_off(p - 1)];
+    for (int k = p - 1; k >= 0; --k) {
+      if (chi_next >= 0 && k <= chi_next + bw + 1) {  // rows chi_next .. enter the ring before their first use
+        park_b(chi_next);
+        chi_next -= CHB;
+        if (chi_next >= 0) fetch_b(chi_next);
+        asm volatile("" ::: "memory");
+      }
+      const double f0 = f0n, zk = zn, fcol = fn;
+      const int kn = k > 0 ? k - 1 : 0;
+      f0n = ring[(kn & 63) * rs];
+      zn = z[kn];
+      fn = ring[col_off(k - 1)];
+      const double acck = readlane_f64(acc, k & 63);
+      const double xk = f0 * (zk - acck);
+      const bool own = lane == (k & 63);
+      acc = own ? 0.0 : fma(fcol, xk, acc);
+      if (own) x[k] = xk;
+    }
+  }
+  asm volatile("" ::: "memory");
+  CAVE_ACC(12);
+}
+#endif  // __HIPCC__
+
 }  // namespace cave

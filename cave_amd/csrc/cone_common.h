@@ -156,6 +156,7 @@ struct SolveWork {
   int ldh;
   // band form only (large-cone path, cone_band.h)
   bool band_hot;   // bwin, bz, step and act all live in LDS (typed fast variant of the band solver)
+  bool band_wave;  // narrow band, everything hot: wave 0 runs solve_spd_band_wave (GPU build only)
   int bw;          // half bandwidth of M M^T in the reduced-row order
   double* bwin;    // [(bw+1)*(bw+1)] ring window of the rows being eliminated
   double* bfac;    // [p*(bw+1)] factor: bfac[k*ldh] = 1/d_k, bfac[k*ldh + t] = row k of the updated band

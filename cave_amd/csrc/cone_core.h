@@ -18,6 +18,17 @@
 //   quadratic model, exact line search on the true f).  proj = y - res*, rnorm = ||res*||_2.
 #pragma once
 #include <type_traits>
+// tunables of the smoothed Hessian / inexact line search (defaults = the shipped values; tools/diag/tune_newton.py
+// rebuilds the serial test build with other values to measure iteration counts)
+#ifndef CAVE_MU_COEF
+#define CAVE_MU_COEF 0.2
+#endif
+#ifndef CAVE_MU_CAP
+#define CAVE_MU_CAP 0.7
+#endif
+#ifndef CAVE_PSITOL
+#define CAVE_PSITOL 1e-1
+#endif
 #if defined(CAVE_STAMPS_FINE)
 #define CAVE_ACCF(slot) CAVE_ACC(slot)
 #else
@@ -693,7 +704,7 @@ CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
   double alpha = 1.0, lo = 0.0, hi = amax, d1 = 0.0, d2 = 0.0;
   // an inexact search is enough for the outer Newton iteration: stop once the slope has dropped to a
   // tenth of its initial value (tighter tolerances cost ~40 % more evaluations for no fewer iterations)
-  const double psitol = 1e-1 * fabs(psi0);
+  const double psitol = CAVE_PSITOL * fabs(psi0);
   for (int ls = 0; ls < 60; ++ls) {
     eval(alpha, d1, d2);
 #ifdef CAVE_TRACE
@@ -797,7 +808,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   bool converged = (p == 0);
   int it = 0;
   CAVE_T0();
-  for (; p > 0 && it < max_iter; ++it, cap07 *= 0.7, sched01 *= 0.1) {
+  for (; p > 0 && it < max_iter; ++it, cap07 *= CAVE_MU_CAP, sched01 *= 0.1) {
     // gradient g = -M Pi(r) and projected-gradient norm
     CAVE_ACCF(22);
     gradient_any<C, PM1>(c, v, rc, w.g);
@@ -952,7 +963,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // (capped by 0.7^it: tied to the gradient alone the scale can hold itself up -- a stalled iteration keeps mu
       // large, and a large mu keeps some cones from converging; the cap is far above pgn/g0n on every
       // instance that converges normally)
-      const double mu = 0.1 * ymax * fmin(pgn / g0n, cap07);
+      const double mu = CAVE_MU_COEF * ymax * fmin(pgn / g0n, cap07);
       const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
       bool done = false;
 #if defined(__HIPCC__)
@@ -1021,6 +1032,16 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         c.sync();
         CAVE_ACC(4);
         if constexpr (BAND) {
+#if defined(__HIPCC__)
+          if (w.band_wave) {
+            if (c.wave_id() == 0)
+              solve_spd_band_wave(c.lane_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg
+#ifdef CAVE_STAMPS
+                                  , c.st
+#endif
+              );
+          } else
+#endif
           if (w.band_hot)
             solve_spd_band<C, true>(c, w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);
           else

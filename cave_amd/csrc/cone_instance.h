@@ -159,7 +159,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     const uint32_t pp = (uint32_t)(p > 0 ? p : 1);
     SolveWork w;
     w.y = y;
-    w.bw = 0; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
+    w.bw = 0; w.band_wave = false; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
     if (mode == MODE_IPM) { warm_theta = nullptr; warm_state = nullptr; }  // the interior iterate is not a starting point
     w.warm = (warm_theta && warm_state && *warm_state == 1) ? warm_theta : nullptr;
     if constexpr (LARGE) {
@@ -168,17 +168,30 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       if ((uint64_t)pp * ld > (1ull << 27) || ld > 4096u) return ST_TOO_LARGE;  // 1 GiB of band per instance
       w.bw = bw;
       w.ldh = (int)ld;
+      // narrow bands: the whole elimination runs on one wave (cone_band.h, solve_spd_band_wave)
+      bool wave_mode = false;
+#if defined(__HIPCC__)
+      if constexpr (C::WL == 64) {
+        const uint64_t need = 8ull * (ld * (uint64_t)band_wave_stride(bw) + 2ull * pp + band_wave_staging(bw)) + pp + 64u;
+        wave_mode = hot != nullptr && band_wave_fits(bw, p) && (uint64_t)(hot->top - hot->off) >= need;
+      }
+#endif
       // small, touched every elimination step / every inner round: LDS first
-      w.bwin = hot_get<double>(hot, ar, ld * ld);
+      w.bwin = hot_get<double>(hot, ar, wave_mode ? ld * (uint32_t)band_wave_stride(bw) : ld * ld);
       w.bz = hot_get<double>(hot, ar, pp);
       w.step = hot_get<double>(hot, ar, pp);
       w.act = hot_get<uint8_t>(hot, ar, pp);
       // staging chunks: as many rows as the prefetch registers hold, fewer if that keeps them in LDS
       w.bch = band_chunk_rows<C>((int)ld);
-      if (hot) {
+      if (wave_mode) w.bch = (int)ld;
+      else if (hot) {
         const uint32_t room = (hot->top - hot->off) / (2u * 8u * ld);
         if (room >= 4u && room < (uint32_t)w.bch) w.bch = (int)room;
       }
+#if defined(__HIPCC__)
+      if (wave_mode) w.bstg = hot_get<double>(hot, ar, band_wave_staging(bw));
+      else
+#endif
       w.bstg = hot_get<double>(hot, ar, 2u * (uint32_t)w.bch * ld);
       w.g2 = hot_get<double>(hot, ar, pp);
       w.ttry = hot_get<double>(hot, ar, pp);
@@ -195,6 +208,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
 #if defined(__HIPCC__)
       w.band_hot = hot && hot->owns(w.bwin) && hot->owns(w.bz) && hot->owns(w.step) && hot->owns(w.act) &&
                    hot->owns(w.bstg);
+      w.band_wave = wave_mode && w.band_hot;
 #endif
     } else {
       if (p > C::PMAX) return ST_TOO_LARGE;
@@ -593,6 +607,22 @@ static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int
   const int64_t p = max_rows > 0 ? max_rows : 1;
   return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 8 * align8u(8 * p) + 2 * align8u(p) +
          align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096 + 256;  // + staging buffers (at most 4096 entries each)
+}
+
+// LDS for the hot arrays of the large-cone path (solve_and_finish<LARGE> allocates in this order: window, z, step,
+// act, staging; what is left takes further row vectors).  Narrow bands: exactly what the one-wave elimination
+// needs, so that four workgroups fit a CU; otherwise a 4 KiB-rounded figure with room for a third row vector.
+static inline uint32_t packed_large_lds_bytes(int64_t max_rows, int64_t max_bw) {
+  const uint64_t p = max_rows > 0 ? max_rows : 1, ld = (uint64_t)max_bw + 1u;
+  if (band_wave_fits((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) {
+    const uint64_t need = 8ull * (ld * (uint64_t)band_wave_stride((int)max_bw) + 2ull * p + band_wave_staging((int)max_bw)) + p + 64u;
+    const uint64_t tot = ((need + 256u + 64u) + 255u) & ~255ull;  // + context scratch, alignment slack
+    if (tot * 4u <= kMaxLds) return (uint32_t)tot;
+  }
+  uint64_t want = 8ull * (ld * (ld + 2u) + 2u * 32u * ld + 3u * p) + p + 4096u;
+  want = (want + 4095u) / 4096u * 4096u;
+  if (want < 32u * 1024u) want = 32u * 1024u;
+  return (uint32_t)(want > kMaxLds ? kMaxLds : want);
 }
 
 // lite_room: reserve the index structures of the one-wave lite solver (only launches of up to 2048 instances use it)

@@ -199,9 +199,7 @@ class ConeStore:
         self.large = self.lds_bytes <= 0 or self.max_rows > 64
         self.band_entries, self.max_bw = self._max_band_entries() if self.large else (0, 0)
         # LDS for the large path's hot arrays: ring window + staging buffers + three row vectors
-        ld = self.max_bw + 1
-        want = 8 * (ld * ld + 2 * 32 * ld + 3 * self.max_rows) + self.max_rows + 4096
-        self.large_lds = int(min(_lib.MAX_LDS, max(32 * 1024, (want + 4095) // 4096 * 4096)))
+        self.large_lds = int(lib.cave_hip_packed_large_lds_bytes(int(self.max_rows), int(self.max_bw))) if self.large else 0
         return self
 
     def _max_band_entries(self) -> int:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 6
+#define CAVE_HIP_ABI_VERSION 7
 
 /* return codes */
 #define CAVE_OK 0
@@ -194,6 +194,11 @@ int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, 
  *   lds_bytes     LDS per workgroup used for the small hot arrays, 0 = 64 KiB */
 int64_t cave_hip_large_slice_bytes(int64_t m_max, int64_t d, int64_t nnz_cap, int64_t band_entries);
 int64_t cave_hip_packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band_entries);
+/* LDS per workgroup that keeps the hot arrays of the band solver (ring window, staging, two row vectors, flags)
+ * on chip for reduced systems of up to max_rows rows and half bandwidth max_bw (v7).  Narrow bands
+ * (max_bw <= 34) are eliminated by ONE wave per instance; the figure returned for them is the exact need, so that
+ * four workgroups share a CU (the 2- and 1-wave forms of cave_hip_cone_packed_large are chosen from it). */
+int32_t cave_hip_packed_large_lds_bytes(int32_t max_rows, int32_t max_bw);
 
 int32_t cave_hip_cone_dense_large(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d,
                                   int32_t mode, float sign, float inner_ratio, int32_t max_iter, int64_t nnz_cap,

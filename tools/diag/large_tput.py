@@ -20,6 +20,7 @@ c = torch.tensor(ctrs, device=dev); p0 = torch.tensor(pred, device=dev)
 t0 = time.time(); st = ConeStore.from_dense(c, chunk=8 if which != "sp30" else 256); torch.cuda.synchronize()
 print(f"{which}: pack {nuniq} instances {time.time()-t0:.2f}s; store {st.nbytes()/1e6:.1f} MB, rows {st.max_rows} bw {st.max_bw} lds {st.large_lds}", flush=True)
 del c
+if os.environ.get("LDS"): st.large_lds = int(os.environ["LDS"])
 for B in Bs:
     ids = torch.arange(B, device=dev) % nuniq
     p = p0[ids] + 0.01 * torch.randn(B, p0.shape[1], device=dev)

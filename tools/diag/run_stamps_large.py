@@ -15,6 +15,8 @@ if which == "sp30": ctrs, costs, _ = synth.sp_batch(30, 30, B, seed=0)
 else: ctrs, costs, _ = synth.tsp_batch(100, B, seed=0)
 c = torch.tensor(ctrs, device="cuda"); p = torch.tensor(costs, device="cuda")
 st = ConeStore.from_dense(c, chunk=8)
+if os.environ.get("LDS"): st.large_lds = int(os.environ["LDS"])
+print("large_lds", st.large_lds)
 ids = torch.arange(B, device="cuda")
 for _ in range(2): o = st.cone_op(ids, p, 0, -1.0)
 buf = (C.c_ulonglong * (16 * B))()
