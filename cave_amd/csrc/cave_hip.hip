@@ -47,7 +47,7 @@ __global__ CAVE_BOUNDS(C) void cone_dense_kernel(DenseParams P) {
   const int64_t b = blockIdx.x;
   if (b >= P.B) return;
 #ifdef CAVE_STAMPS
-  for (int i = 0; i < 16; ++i) c.st[i] = 0;
+  for (int i = 0; i < 32; ++i) c.st[i] = 0;
   unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   run_dense_instance(c, smem, P, b);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(C::NT, MINB) void cone_packed_large_kernel(PackedPa
   unsigned char* ws = W.base + (uint64_t)blockIdx.x * W.slice;
   for (int64_t b = blockIdx.x; b < P.B; b += gridDim.x) {
 #ifdef CAVE_STAMPS
-    for (int i = 0; i < 16; ++i) c.st[i] = 0;
+    for (int i = 0; i < 32; ++i) c.st[i] = 0;
     unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     run_packed_large_instance<C>(c, smem, P, b, ws, (uint32_t)W.slice);

@@ -383,16 +383,22 @@ CAVE_HOSTDEV bool band_wave_fits(int bw, int p) {
   if ((bw + 1) * (bw + 1) > 64 * kBandWaveRegs) return false;
   return band_wave_duos(bw) <= 64 * kBandWaveDuos;
 }
-// window row stride: one zero pad column (the second operand of a duo that has no second entry reads it), odd so
-// that consecutive rows start on different banks
-CAVE_HOSTDEV int band_wave_stride(int bw) { return ((bw + 2) & 1) ? bw + 2 : bw + 3; }
-
-// staging entries: two chunks of bw + 1 raw rows on the way down, a 64-row ring of factor rows on the way back
-CAVE_HOSTDEV uint32_t band_wave_staging(int bw) {
-  const uint32_t ld = (uint32_t)bw + 1u, a = 2u * ld * ld, b = 64u * ld + 1u;
+// window row stride: odd, so that consecutive rows start on different banks
+CAVE_HOSTDEV int band_wave_stride(int bw) { return ((bw + 1) & 1) ? bw + 1 : bw + 2; }
+constexpr int kBandBlock = 4;  // pivots eliminated per step
+// window entries: a ring of bw + kBandBlock rows (a block of pivot rows + every row the block reaches)
+CAVE_HOSTDEV uint32_t band_wave_window(int bw) { return (uint32_t)(bw + kBandBlock) * (uint32_t)band_wave_stride(bw); }
+// operand scratch of one block step: the pivot rows and the multipliers, kBandBlock entries per column, columns
+// kBandBlock .. bw + kBandBlock + 1 (the last one is a zero column: second operand of a duo without a second entry)
+CAVE_HOSTDEV uint32_t band_wave_scratch(int bw) { return 2u * (uint32_t)kBandBlock * (uint32_t)(bw + kBandBlock + 2); }
+// staging entries: two chunks of bw + 1 raw rows on the way down, a 64-row ring of factor rows on the way back.  The
+// scratch lives in x (unused until the back substitution) when p is large enough, else behind the staging chunks.
+CAVE_HOSTDEV uint32_t band_wave_staging(int bw, int p) {
+  const uint32_t ld = (uint32_t)bw + 1u, b = 64u * ld + 1u;
+  uint32_t a = 2u * ld * ld;
+  if ((uint32_t)p < band_wave_scratch(bw)) a += band_wave_scratch(bw);
   return a > b ? a : b;
 }
-
 
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------ narrow bands on ONE wave
@@ -424,11 +430,25 @@ __device__ __forceinline__ T* uniform_ptr(T* q) {  // arguments of a real call a
   return (T*)(((uint64_t)hi << 32) | lo);
 }
 
-CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* Hb_v, const int bw_v, const double* rhs_v,
-                                                  const uint8_t* act_v, const int p_v, const double reg_rel, double* win_v,
-                                                  double* fac_v, double* z_v, double* x_v, double* stg_v,
-                                                  unsigned long long* stamps = nullptr) {
-  constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs;
+// The elimination advances kBandBlock = 4 pivots per step:
+//   A  the four pivot rows are read into registers (lane t = column k + t, lane 63 = the right-hand side) and
+//      eliminated against each other there (v_readlane broadcasts, no LDS traffic);
+//   B  pivot rows P[t][0..3] and multipliers Q[t][0..3] = P * (1/d) go to an LDS scratch as 32-byte records, the
+//      finished rows to the factor (workspace);
+//   C  every duo of the trailing triangle takes its four updates in one pass: 2 + 4 ds_read_b128 of operands whose
+//      addresses never change, one ds_read2_b64 / ds_write2_b64 of the target -- a quarter of the LDS round trips and
+//      of the address arithmetic of a pivot-at-a-time loop (measured on a 30x30 grid: ~1190 cycles per pivot there,
+//      issue- and latency-bound at ~130 instructions per pivot on a lone wave);
+//   D  the right-hand side below the block; E  four new rows take the slots of the four retired ones.
+// Every entry receives the same fma sequence as in a pivot-at-a-time elimination, so the bits are the same.
+// NW = waves in the workgroup: waves 1.. return at once (the caller's barrier follows).
+template <int NW>
+CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave_v, const double* Hb_v, const int bw_v,
+                                                  const double* rhs_v, const uint8_t* act_v, const int p_v,
+                                                  const double reg_rel, double* win_v, double* fac_v, double* z_v,
+                                                  double* x_v, double* stg_v, unsigned long long* stamps = nullptr) {
+  constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs, NB = kBandBlock;
+  if (__builtin_amdgcn_readfirstlane(wave_v) != 0) return;
   const int bw = __builtin_amdgcn_readfirstlane(bw_v), p = __builtin_amdgcn_readfirstlane(p_v);
   const double* Hb_ = uniform_ptr(Hb_v);
   const double* rhs = uniform_ptr(rhs_v);
@@ -442,7 +462,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* 
   struct { unsigned long long* st; } c{stamps};
 #endif
   CAVE_T0();
-  const int ld = bw + 1, wl = band_wave_stride(bw), csz = ld * ld, wsz = ld * wl;
+  const int ld = bw + 1, wl = band_wave_stride(bw), csz = ld * ld, R = bw + NB, wsz = R * wl;
   auto Hb = space_cast<1>(Hb_);
   auto fac = space_cast<1>(fac_);
   auto act = space_cast<3>(act_);
@@ -450,6 +470,10 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* 
   auto z = space_cast<3>(z_);
   auto x = space_cast<3>(x_);
   auto stg = space_cast<3>(stg_);
+  // operand scratch: P[t][a] = U[k+a][k+t], Q[t][a] = P[t][a] / d_a, t = NB .. bw + NB + 1 (last column: zeros)
+  const int ncol = bw + NB + 2;
+  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : stg + 2 * csz;
+  auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;
   for (int i = lane; i < p; i += 64) {
@@ -484,93 +508,178 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* 
       if (idx < csz) stg[b * csz + idx] = regs[j];
     }
   };
-  // rows 0 .. bw of the band as the elimination sees them, pad columns zero
+  // rows 0 .. R-1 of the band as the elimination sees them (rows past the end of the matrix are zero rows)
   for (int idx = lane; idx < wsz; idx += 64) {
     const int r = idx / wl, t = idx - r * wl;
     win[idx] = (t <= bw) ? band_row_entry(Hb, ld, act, p, reg, r, t) : 0.0;
   }
-  // chunk c = raw rows ld + c*ld .. of H; chunk c is consumed from buffer c & 1 while pivots c*ld .. run
-  fetch(Hb, ld * ld, p * ld);
+  // chunk c = raw rows R + c*ld .. of H; chunk c is consumed from buffer c & 1
+  fetch(Hb, R * ld, p * ld);
   park(0);
-  fetch(Hb, 2 * ld * ld, p * ld);
-  // this lane's duos: duo q in row-major order over rows s = 1 .. bw (entries t = s, s+2, ...), q = lane + 64 u
-  // (a lane without a duo in the last round repeats duo q mod nd: two lanes then store the same bits to the same
-  //  address, which needs no predicate -- a predicated store drags its loads into the branch, one more LDS round trip)
-  int ua[U], ub[U], ur[U];
+  fetch(Hb, (R + ld) * ld, p * ld);
+  park(1);
+  fetch(Hb, (R + 2 * ld) * ld, p * ld);
+  // this lane's duos: duo q in row-major order over rows s = 1 .. bw below the block (entries t = s, s+2, ...),
+  // q = lane + 64 u.  A lane past the end of the last round repeats a duo of the same round: two lanes then store
+  // the same bits to the same address (all loads of a step precede its stores), which needs no predicate.
+  int uq[U], up[U], ur[U];
   const int nd = band_wave_duos(bw);
+  const int nu = (nd + 63) / 64;
   {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int q = lane + 64 * u, s = 1;
-      q = q < nd ? q : q % nd;
+    for (int i = 0; i < U; ++i) {
+      int nv = nd - 64 * i;
+      nv = nv > 64 ? 64 : (nv < 1 ? 1 : nv);
+      int q = 64 * i + (lane < nv ? lane : lane % nv), s = 1;
+      q = q < nd ? q : 0;
       while (q >= (bw - s + 2) / 2) { q -= (bw - s + 2) / 2; ++s; }
       const int t = s + 2 * q;
-      ua[u] = s;
-      ub[u] = t;                    // t + 1 = bw + 1 is the zero pad column
-      ur[u] = s * wl + (t - s);     // target, relative to the pivot row's slot
+      uq[i] = NB * (s + NB - 1);        // record of column k + NB - 1 + s in Q
+      up[i] = NB * (t + NB - 1);        // ... of column k + NB - 1 + t (and the next one) in P
+      ur[i] = (s + NB - 1) * wl + (t - s);  // target, relative to the first pivot row's slot
     }
   }
-  const int nu = (nd + 63) / 64;
+  // zero column of the scratch, written once
+  if (lane < NB) { scrP[NB * (ncol - 1) + lane] = 0.0; scrQ[NB * (ncol - 1) + lane] = 0.0; }
   asm volatile("" ::: "memory");
   CAVE_ACC(10);
   auto eliminate = [&](auto nu_tag) __attribute__((always_inline)) {
     constexpr int NU = decltype(nu_tag)::value;
-    int slot_k = 0, cidx = 0;
-    for (int k = 0; k < p; ++k) {
-      const int base_k = slot_k * wl;
-      auto wk = win + base_k;
-      if (slot_k == 0) {  // first row of chunk cidx: chunk cidx+1 (registers) takes the buffer chunk cidx-1 has left
-        park((cidx + 1) & 1);
-        fetch(Hb, (cidx + 3) * csz, p * ld);
-      }
-      // ---- loads
-      const double dk = wk[0];
-      const double zk = z[k];
-      double pa[NU], pb0[NU], pb1[NU], pr0[NU], pr1[NU];
-      int poff[NU];
+    int slot_k = 0, cidx = 0, cpos = 0;
+    const bool zl = lane == 63;
+    for (int k = 0; k < p; k += NB) {
+      // ---- A: pivot rows k .. k+3 into registers; lane t holds column k + t (entry t - a of row k + a)
+      double u[NB];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        int o = base_k + ur[u];
-        o = o >= wsz ? o - wsz : o;
-        poff[u] = o;
-        pa[u] = wk[ua[u]];
-        pb0[u] = wk[ub[u]];
-        pb1[u] = wk[ub[u] + 1];
-        pr0[u] = win[o];
-        pr1[u] = win[o + 1];
+      for (int a = 0; a < NB; ++a) {
+        int sl = slot_k + a;
+        sl = sl >= R ? sl - R : sl;
+        const int off = lane - a;
+        const bool in = off >= 0 && off <= bw;
+        const double v = win[sl * wl + (in ? off : 0)];
+        const double zv = z[k + a < p ? k + a : p - 1];
+        u[a] = zl ? (k + a < p ? zv : 0.0) : (in ? v : 0.0);
       }
-      const bool zown = lane < bw && k + 1 + lane < p;
-      const double zw = wk[lane < bw ? 1 + lane : 0];
-      const double zz = z[zown ? k + 1 + lane : k];
-      const bool town = lane <= bw;
-      const double rold = wk[town ? lane : 0];
-      const int rI = k + ld;
-      const bool rin = town && rI + lane < p;
-      const double raw = stg[(cidx & 1) * csz + slot_k * ld + (town ? lane : 0)];
-      const bool aI = act[rI < p ? rI : p - 1] != 0, aJ = act[rin ? rI + lane : p - 1] != 0;
-      // ---- compute
-      const bool ok = dk > 1e-300;
-      double inv = rcp_full(ok ? dk : 1.0);
-      inv = ok ? inv : 0.0;
-      // ---- stores
+      double inv[NB];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const double m = pa[u] * inv;
-        win[poff[u]] = fma(-m, pb0[u], pr0[u]);
-        win[poff[u] + 1] = fma(-m, pb1[u], pr1[u]);
+      for (int a = 0; a < NB; ++a) {
+        const double d = readlane_f64(u[a], a);
+        const bool ok = d > 1e-300;
+        double iv = rcp_full(ok ? d : 1.0);
+        iv = ok ? iv : 0.0;
+        inv[a] = iv;
+#pragma unroll
+        for (int b = a + 1; b < NB; ++b) {
+          const double m = readlane_f64(u[a], b) * iv;
+          u[b] = fma(-m, u[a], u[b]);
+        }
       }
-      if (zown) z[k + 1 + lane] = fma(-zw * inv, zk, zz);
-      if (town) {
-        fac[k * ld + lane] = (lane == 0) ? inv : rold;
-        double rnew = 0.0;
-        if (rin) rnew = (lane == 0) ? (aI ? 1.0 : raw + reg) : ((aI || aJ) ? 0.0 : raw);
-        wk[lane] = rnew;  // row k + bw + 1 takes the slot row k leaves
+      CAVE_ACCF(0);
+      // ---- B: operands of the trailing update, finished rows
+      if (lane >= NB && lane < ncol - 1) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          scrP[NB * lane + a] = u[a];
+          scrQ[NB * lane + a] = u[a] * inv[a];
+        }
       }
-      if (++slot_k == ld) { slot_k = 0; ++cidx; }
+      double zq[NB];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        zq[a] = readlane_f64(u[a], 63);
+        const int off = lane - a;
+        if (off >= 0 && off <= bw && k + a < p) fac[(k + a) * ld + off] = (off == 0) ? inv[a] : u[a];
+      }
+      if (zl) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+          if (k + a < p) z[k + a] = u[a];
+      }
       asm volatile("" ::: "memory");
+      CAVE_ACCF(1);
+      // ---- C: trailing triangle
+      const int base_k = slot_k * wl;
+      double qv[NU > 0 ? NU : 1][NB], p0[NU > 0 ? NU : 1][NB], p1[NU > 0 ? NU : 1][NB], r0[NU > 0 ? NU : 1], r1[NU > 0 ? NU : 1];
+      int poff[NU > 0 ? NU : 1];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        int o = base_k + ur[i];
+        o = o >= wsz ? o - wsz : o;
+        poff[i] = o;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          qv[i][a] = scrQ[uq[i] + a];
+          p0[i][a] = scrP[up[i] + a];
+          p1[i][a] = scrP[up[i] + NB + a];
+        }
+        r0[i] = win[o];
+        r1[i] = win[o + 1];
+      }
+      // ---- D: right-hand side below the block (lane i: row k + NB + i)
+      const bool zown = lane < bw && k + NB + lane < p;
+      double zqv[NB];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) zqv[a] = scrQ[NB * (NB + (lane < bw ? lane : 0)) + a];
+      double zz = z[zown ? k + NB + lane : 0];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          r0[i] = fma(-qv[i][a], p0[i][a], r0[i]);
+          r1[i] = fma(-qv[i][a], p1[i][a], r1[i]);
+        }
+        win[poff[i]] = r0[i];
+        win[poff[i] + 1] = r1[i];
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a) zz = fma(-zqv[a], zq[a], zz);
+      if (zown) z[k + NB + lane] = zz;
+      CAVE_ACCF(9);
+      // ---- E: rows k + R .. k + R + 3 take the slots of the four retired ones.  All loads first, from clamped
+      // addresses, and the masks as selects: written with an `if`, each row pays two dependent LDS round trips
+      // (the loads are sunk into the branch) -- measured at ~490 cycles per row, more than the elimination itself.
+      {
+        const int tl = lane <= bw ? lane : bw;
+        double raw[NB];
+        uint32_t fI[NB], fJ[NB];
+        int dst[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          int cp = cpos + a, cb = cidx;
+          if (cp >= ld) { cp -= ld; ++cb; }
+          int sl = slot_k + a;
+          sl = sl >= R ? sl - R : sl;
+          dst[a] = sl * wl + tl;
+          const int rI = k + R + a;
+          raw[a] = stg[(cb & 1) * csz + cp * ld + tl];
+          fI[a] = act[rI < p ? rI : p - 1];
+          fJ[a] = act[rI + tl < p ? rI + tl : p - 1];
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const int rI = k + R + a;
+          const bool fixed = (fI[a] | fJ[a]) != 0u;
+          const double diag = fI[a] != 0u ? 1.0 : raw[a] + reg;
+          double v = (lane == 0) ? diag : (fixed ? 0.0 : raw[a]);
+          v = (rI + tl < p) ? v : 0.0;
+          if (lane <= bw) win[dst[a]] = v;
+        }
+        cpos += NB;
+        if (cpos >= ld) {  // into chunk cidx + 1: chunk cidx + 2 (registers) takes the buffer chunk cidx has left
+          cpos -= ld;
+          ++cidx;
+          park((cidx + 1) & 1);
+          fetch(Hb, (R + (cidx + 2) * ld) * ld, p * ld);
+        }
+      }
+      slot_k += NB;
+      slot_k = slot_k >= R ? slot_k - R : slot_k;
+      asm volatile("" ::: "memory");
+      CAVE_ACCF(11);
     }
   };
   switch (nu) {
+    case 0: eliminate(std::integral_constant<int, 0>{}); break;
     case 1: eliminate(std::integral_constant<int, 1>{}); break;
     case 2: eliminate(std::integral_constant<int, 2>{}); break;
     case 3: eliminate(std::integral_constant<int, 3>{}); break;
@@ -581,6 +690,9 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* 
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   CAVE_ACC(11);
+#ifdef CAVE_STAMPS
+  c.st[13] += (unsigned long long)p;  // pivots eliminated (per-pivot cost = slot 11 / slot 13)
+#endif
   // ---- back substitution  x_k = inv_k (z_k - sum_s U[k][k+s] x_{k+s}), column oriented.
   // Factor rows come back through a 64-row ring in LDS (row r in slot r & 63; one zero entry behind the ring), so lane l
   // finds every row it owns at l * ld: the entry of column k in its row is at offset s = k - row, and an offset past
@@ -607,7 +719,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* 
   };
   int chi_next = p - 1;  // top row of the chunk in flight
   fetch_b(chi_next);
-  while (chi_next >= 0 && chi_next + bw + 1 >= p - 1) {
+  while (chi_next >= 0 && chi_next + bw + NB >= p - 1) {
     park_b(chi_next);
     chi_next -= CHB;
     if (chi_next >= 0) fetch_b(chi_next);
@@ -616,28 +728,65 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const double* 
   {
     double acc = 0.0;  // partial sum of the row this lane owns (row = lane mod 64)
     const int rowbase = lane * rs;
-    auto col_off = [&](int k) -> int {  // offset of column k in this lane's row, clamped onto the zero entry
-      const int sft = 1 + ((k - 1 - lane) & 63);
-      return sft < ld ? rowbase + sft : zero_at;
-    };
-    double f0n = ring[((p - 1) & 63) * rs], zn = z[p - 1], fn = ring[col_off(p - 1)];
-    for (int k = p - 1; k >= 0; --k) {
-      if (chi_next >= 0 && k <= chi_next + bw + 1) {  // rows chi_next .. enter the ring before their first use
+    auto admit = [&](int k) __attribute__((always_inline)) {  // rows chi_next .. enter the ring before their first use
+      if (chi_next >= 0 && k <= chi_next + bw + NB) {
         park_b(chi_next);
         chi_next -= CHB;
         if (chi_next >= 0) fetch_b(chi_next);
         asm volatile("" ::: "memory");
       }
-      const double f0 = f0n, zk = zn, fcol = fn;
-      const int kn = k > 0 ? k - 1 : 0;
-      f0n = ring[(kn & 63) * rs];
-      zn = z[kn];
-      fn = ring[col_off(k - 1)];
-      const double acck = readlane_f64(acc, k & 63);
-      const double xk = f0 * (zk - acck);
+    };
+    // entry t of factor row r, zero past the band (scalar address: every lane reads the same word)
+    auto entry = [&](int r, int t) -> double { return ring[t <= bw ? (r & 63) * rs + t : zero_at]; };
+    int k = p - 1;
+    // the p mod NB rows at the bottom, one at a time
+    for (; k >= 0 && ((k + 1) % NB) != 0; --k) {
+      admit(k);
+      const int sft = 1 + ((k - 1 - lane) & 63);
+      const double fcol = ring[sft < ld ? rowbase + sft : zero_at];
+      const double xk = ring[(k & 63) * rs] * (z[k] - readlane_f64(acc, k & 63));
       const bool own = lane == (k & 63);
       acc = own ? 0.0 : fma(fcol, xk, acc);
       if (own) x[k] = xk;
+      asm volatile("" ::: "memory");
+    }
+    // then NB = 4 rows per step: the four unknowns from one batch of loads (the 4x4 triangle between them as
+    // scalars), after which every lane folds all four into its row's partial sum -- same fma order as row by row
+    for (; k >= NB - 1; k -= NB) {
+      admit(k);
+      const int s0 = 1 + ((k - 1 - lane) & 63);  // offset of column k in this lane's row; column k - j: s0 - j
+      double fc[NB];
+      bool fin[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int sj = s0 - j;
+        fin[j] = sj >= 1 && sj <= bw;
+        fc[j] = ring[rowbase + (fin[j] ? sj : 0)];
+      }
+      double f0[NB], zz[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { f0[j] = ring[((k - j) & 63) * rs]; zz[j] = z[k - j]; }
+      const double c10 = entry(k - 1, 1), c20 = entry(k - 2, 2), c21 = entry(k - 2, 1), c30 = entry(k - 3, 3),
+                   c31 = entry(k - 3, 2), c32 = entry(k - 3, 1);
+      const double x0 = f0[0] * (zz[0] - readlane_f64(acc, k & 63));
+      double a1 = readlane_f64(acc, (k - 1) & 63), a2 = readlane_f64(acc, (k - 2) & 63), a3 = readlane_f64(acc, (k - 3) & 63);
+      a1 = fma(c10, x0, a1);
+      const double x1 = f0[1] * (zz[1] - a1);
+      a2 = fma(c20, x0, a2);
+      a2 = fma(c21, x1, a2);
+      const double x2 = f0[2] * (zz[2] - a2);
+      a3 = fma(c30, x0, a3);
+      a3 = fma(c31, x1, a3);
+      a3 = fma(c32, x2, a3);
+      const double x3 = f0[3] * (zz[3] - a3);
+      acc = fma(fin[0] ? fc[0] : 0.0, x0, acc);
+      acc = fma(fin[1] ? fc[1] : 0.0, x1, acc);
+      acc = fma(fin[2] ? fc[2] : 0.0, x2, acc);
+      acc = fma(fin[3] ? fc[3] : 0.0, x3, acc);
+      const int mine = (k - lane) & 63;  // < NB: this lane owned one of the four rows; its sum starts over
+      acc = mine < NB ? 0.0 : acc;
+      if (lane < NB) x[k - lane] = lane == 0 ? x0 : (lane == 1 ? x1 : (lane == 2 ? x2 : x3));
+      asm volatile("" ::: "memory");
     }
   }
   asm volatile("" ::: "memory");

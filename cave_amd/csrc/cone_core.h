@@ -26,6 +26,15 @@
 #ifndef CAVE_MU_CAP
 #define CAVE_MU_CAP 0.7
 #endif
+#ifndef CAVE_BMU0
+#define CAVE_BMU0 0.1      // band form: first smoothing scale (x max|y|), its decay per iteration, and the gradient-tied floor
+#endif
+#ifndef CAVE_BMU_DECAY
+#define CAVE_BMU_DECAY 0.1
+#endif
+#ifndef CAVE_BMU_COEF
+#define CAVE_BMU_COEF 0.03
+#endif
 #ifndef CAVE_PSITOL
 #define CAVE_PSITOL 1e-1
 #endif
@@ -808,7 +817,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   bool converged = (p == 0);
   int it = 0;
   CAVE_T0();
-  for (; p > 0 && it < max_iter; ++it, cap07 *= CAVE_MU_CAP, sched01 *= 0.1) {
+  for (; p > 0 && it < max_iter; ++it, cap07 *= CAVE_MU_CAP, sched01 *= CAVE_BMU_DECAY) {
     // gradient g = -M Pi(r) and projected-gradient norm
     CAVE_ACCF(22);
     gradient_any<C, PM1>(c, v, rc, w.g);
@@ -882,8 +891,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // When the whole band fits the (idle) LDS ring window -- dense reduced systems, p <= bw + 1: TSP --
       // it is accumulated there with LDS atomics and copied out; otherwise straight into the workspace.
       const bool in_lds = w.band_hot && p <= ldh;
-      double mu = (it < 6) ? 0.1 * ymax * sched01 : 0.0;
-      mu = fmax(mu, 0.03 * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
+      double mu = (it < 6) ? CAVE_BMU0 * ymax * sched01 : 0.0;
+      mu = fmax(mu, CAVE_BMU_COEF * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
       auto weight = [&](int k) -> double {
         const uint8_t u = v.usign[k];
         if (u == 0) return 1.0;
@@ -1034,8 +1043,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         if constexpr (BAND) {
 #if defined(__HIPCC__)
           if (w.band_wave) {
-            if (c.wave_id() == 0)
-              solve_spd_band_wave(c.lane_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg
+            solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg
 #ifdef CAVE_STAMPS
                                   , c.st
 #endif

@@ -172,12 +172,12 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       bool wave_mode = false;
 #if defined(__HIPCC__)
       if constexpr (C::WL == 64) {
-        const uint64_t need = 8ull * (ld * (uint64_t)band_wave_stride(bw) + 2ull * pp + band_wave_staging(bw)) + pp + 64u;
+        const uint64_t need = 8ull * (band_wave_window(bw) + 2ull * pp + band_wave_staging(bw, p)) + pp + 64u;
         wave_mode = hot != nullptr && band_wave_fits(bw, p) && (uint64_t)(hot->top - hot->off) >= need;
       }
 #endif
       // small, touched every elimination step / every inner round: LDS first
-      w.bwin = hot_get<double>(hot, ar, wave_mode ? ld * (uint32_t)band_wave_stride(bw) : ld * ld);
+      w.bwin = hot_get<double>(hot, ar, wave_mode ? band_wave_window(bw) : ld * ld);
       w.bz = hot_get<double>(hot, ar, pp);
       w.step = hot_get<double>(hot, ar, pp);
       w.act = hot_get<uint8_t>(hot, ar, pp);
@@ -189,7 +189,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
         if (room >= 4u && room < (uint32_t)w.bch) w.bch = (int)room;
       }
 #if defined(__HIPCC__)
-      if (wave_mode) w.bstg = hot_get<double>(hot, ar, band_wave_staging(bw));
+      if (wave_mode) w.bstg = hot_get<double>(hot, ar, band_wave_staging(bw, p));
       else
 #endif
       w.bstg = hot_get<double>(hot, ar, 2u * (uint32_t)w.bch * ld);
@@ -615,7 +615,7 @@ static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int
 static inline uint32_t packed_large_lds_bytes(int64_t max_rows, int64_t max_bw) {
   const uint64_t p = max_rows > 0 ? max_rows : 1, ld = (uint64_t)max_bw + 1u;
   if (band_wave_fits((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) {
-    const uint64_t need = 8ull * (ld * (uint64_t)band_wave_stride((int)max_bw) + 2ull * p + band_wave_staging((int)max_bw)) + p + 64u;
+    const uint64_t need = 8ull * (band_wave_window((int)max_bw) + 2ull * p + band_wave_staging((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) + p + 64u;
     const uint64_t tot = ((need + 256u + 64u) + 255u) & ~255ull;  // + context scratch, alignment slack
     if (tot * 4u <= kMaxLds) return (uint32_t)tot;
   }

@@ -76,7 +76,7 @@ struct BlockCtx {
   uint32_t par;
   Scratch* sc;
 #ifdef CAVE_STAMPS
-  unsigned long long st[16];
+  unsigned long long st[32];  // [0,16) exported per instance; [16,32) scratch slots of the fine stamps
 #endif
   __device__ __forceinline__ void init(unsigned char* smem) {
     t = (int)threadIdx.x;

@@ -22,7 +22,7 @@ struct WaveCtx {
   static constexpr int WL = 64;          // lanes per wave
   int lane;
 #ifdef CAVE_STAMPS
-  unsigned long long st[16];
+  unsigned long long st[32];  // [0,16) exported per instance; [16,32) scratch slots of the fine stamps
 #endif
   __device__ __forceinline__ void init(unsigned char*) { lane = (int)threadIdx.x; }
   __device__ __forceinline__ void broadcast_from_wave0(double&, int&, int&) const {}

@@ -3,7 +3,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from cave_amd import _lib, synth
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcave_hip_stamps.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("STAMPS_SO", "libcave_hip_stamps.so"))
 from cave_amd.dataset import ConeStore
 lib = _lib.load()
 names = ["scan+build", "load y/avg", "grad+pgn", "hessian", "inner misc", "solve_spd total", "ls setup + gather q",
@@ -24,5 +24,8 @@ lib.cave_hip_debug_stamps(buf, B)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(B, 16).astype(np.float64)
 mean = a.mean(0); tot = mean[14]
 print(f"{which} B={B}: iters mean {o['iters'].float().mean():.2f}; cycles/instance {tot:.0f} = {mean[15]/100:.1f} us")
+if "fine" in os.environ.get("STAMPS_SO", ""):
+    print(f"  per pivot (fine stamps): block A {mean[0]/mean[13]:.0f}  B {mean[1]/mean[13]:.0f}  C+D {mean[9]/mean[13]:.0f}  E {mean[11]/mean[13]:.0f}")
+if mean[13] > 0: print(f"  per pivot: factor {mean[11]/mean[13]:.0f} cycles, back-subst {mean[12]/mean[13]:.0f} cycles")
 for i, n in enumerate(names):
     print(f"  {n:45s} {mean[i]:12.0f}  {100*mean[i]/tot:5.1f}%")
