@@ -370,6 +370,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
 }
 
 // ---- sizing of the one-wave form below (shared with the host code: cone_instance.h, cave_hip.hip)
+constexpr int kBandBlock = 4;      // pivots eliminated per step
 constexpr int kBandWaveDuos = 5;   // duos per lane
 constexpr int kBandWaveRegs = 20;  // prefetch registers per lane: one staged chunk = bw + 1 rows
 
@@ -379,13 +380,15 @@ CAVE_HOSTDEV int band_wave_duos(int bw) {
   return nd;
 }
 CAVE_HOSTDEV bool band_wave_fits(int bw, int p) {
-  if (bw < 1 || p <= bw + 1) return false;
+  // Half bandwidths below kBandBlock stay on the team form.  With two waves the rows admitted for step k - 4
+  // (k + bw .. k + bw + 3) are written while wave 0 reads the pivot rows k .. k + 3 of step k: disjoint only for
+  // bw >= 4 (found by the banded inequality cones of tests/test_gpu_round2.py: bw = 3 raced in the 2-wave kernel).
+  if (bw < kBandBlock || p <= bw + 1) return false;
   if ((bw + 1) * (bw + 1) > 64 * kBandWaveRegs) return false;
   return band_wave_duos(bw) <= 64 * kBandWaveDuos;
 }
 // window row stride: odd, so that consecutive rows start on different banks
 CAVE_HOSTDEV int band_wave_stride(int bw) { return ((bw + 1) & 1) ? bw + 1 : bw + 2; }
-constexpr int kBandBlock = 4;  // pivots eliminated per step
 // window entries: a ring of bw + kBandBlock rows (a block of pivot rows + every row the block reaches)
 CAVE_HOSTDEV uint32_t band_wave_window(int bw) { return (uint32_t)(bw + kBandBlock) * (uint32_t)band_wave_stride(bw); }
 // operand scratch of one block step: the pivot rows and the multipliers, kBandBlock entries per column, columns
@@ -393,9 +396,10 @@ CAVE_HOSTDEV uint32_t band_wave_window(int bw) { return (uint32_t)(bw + kBandBlo
 CAVE_HOSTDEV uint32_t band_wave_scratch(int bw) { return 2u * (uint32_t)kBandBlock * (uint32_t)(bw + kBandBlock + 2); }
 // staging entries: two chunks of bw + 1 raw rows on the way down, a 64-row ring of factor rows on the way back.  The
 // scratch lives in x (unused until the back substitution) when p is large enough, else behind the staging chunks.
+CAVE_HOSTDEV int band_wave_chunk(int bw) { return bw + 1 < 2 * kBandBlock ? 2 * kBandBlock : bw + 1; }  // rows per staged chunk
 CAVE_HOSTDEV uint32_t band_wave_staging(int bw, int p) {
   const uint32_t ld = (uint32_t)bw + 1u, b = 64u * ld + 1u;
-  uint32_t a = 2u * ld * ld;
+  uint32_t a = 2u * (uint32_t)band_wave_chunk(bw) * ld;
   if ((uint32_t)p < band_wave_scratch(bw)) a += band_wave_scratch(bw);
   return a > b ? a : b;
 }
@@ -441,15 +445,28 @@ __device__ __forceinline__ T* uniform_ptr(T* q) {  // arguments of a real call a
 //      issue- and latency-bound at ~130 instructions per pivot on a lone wave);
 //   D  the right-hand side below the block; E  four new rows take the slots of the four retired ones.
 // Every entry receives the same fma sequence as in a pivot-at-a-time elimination, so the bits are the same.
-// NW = waves in the workgroup: waves 1.. return at once (the caller's barrier follows).
+// NW = waves in the workgroup.  NW >= 2: wave 0 runs A and B of a step while wave 1 admits the rows of the PREVIOUS
+// step (E), a workgroup barrier, then both waves share C (duo rounds u = wave, wave + 2, ..) and wave 1 does D, a
+// second barrier; waves 2.. only attend the barriers.  The back substitution stays on wave 0.
 template <int NW>
 CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave_v, const double* Hb_v, const int bw_v,
                                                   const double* rhs_v, const uint8_t* act_v, const int p_v,
                                                   const double reg_rel, double* win_v, double* fac_v, double* z_v,
                                                   double* x_v, double* stg_v, unsigned long long* stamps = nullptr) {
   constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs, NB = kBandBlock;
-  if (__builtin_amdgcn_readfirstlane(wave_v) != 0) return;
+  constexpr int NWE = NW >= 2 ? 2 : 1;  // waves that share the elimination
+  const int wave = __builtin_amdgcn_readfirstlane(wave_v);
   const int bw = __builtin_amdgcn_readfirstlane(bw_v), p = __builtin_amdgcn_readfirstlane(p_v);
+  auto bar = [&]() __attribute__((always_inline)) {  // orders the LDS traffic of the waves
+    if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("" ::: "memory");
+  };
+  if (wave >= NWE) {
+    bar();
+    for (int k = 0; k < p; k += NB) { bar(); bar(); }
+    return;
+  }
+  const bool w0 = wave == 0, wlast = wave == NWE - 1;
   const double* Hb_ = uniform_ptr(Hb_v);
   const double* rhs = uniform_ptr(rhs_v);
   const uint8_t* act_ = uniform_ptr(act_v);
@@ -462,7 +479,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   struct { unsigned long long* st; } c{stamps};
 #endif
   CAVE_T0();
-  const int ld = bw + 1, wl = band_wave_stride(bw), csz = ld * ld, R = bw + NB, wsz = R * wl;
+  const int ld = bw + 1, wl = band_wave_stride(bw), CH = band_wave_chunk(bw), csz = CH * ld, R = bw + NB, wsz = R * wl;
   auto Hb = space_cast<1>(Hb_);
   auto fac = space_cast<1>(fac_);
   auto act = space_cast<3>(act_);
@@ -472,7 +489,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   auto stg = space_cast<3>(stg_);
   // operand scratch: P[t][a] = U[k+a][k+t], Q[t][a] = P[t][a] / d_a, t = NB .. bw + NB + 1 (last column: zeros)
   const int ncol = bw + NB + 2;
-  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : stg + 2 * csz;
+  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : stg + 2 * csz;  // (csz = one staged chunk)
   auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;
@@ -483,15 +500,16 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   md = wave_max_f64(md);
   nfix = wave_sum_u32(nfix);
   const double reg = reg_rel * md;
-  for (int i = lane; i < p; i += 64) {
-    double zi = rhs[i];
-    if (nfix != 0u && !act[i]) {
-      const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
-      for (int j = j0; j <= j1; ++j)
-        if (act[j]) zi -= ((i >= j) ? Hb[j * ld + (i - j)] : Hb[i * ld + (j - i)]) * rhs[j];
+  if (w0)
+    for (int i = lane; i < p; i += 64) {
+      double zi = rhs[i];
+      if (nfix != 0u && !act[i]) {
+        const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
+        for (int j = j0; j <= j1; ++j)
+          if (act[j]) zi -= ((i >= j) ? Hb[j * ld + (i - j)] : Hb[i * ld + (j - i)]) * rhs[j];
+      }
+      z[i] = zi;
     }
-    z[i] = zi;
-  }
   double regs[RMAX];
   auto fetch = [&](decltype(Hb) src, int e0, int eend) {  // unconditional loads from clamped indices
 #pragma unroll
@@ -509,28 +527,33 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     }
   };
   // rows 0 .. R-1 of the band as the elimination sees them (rows past the end of the matrix are zero rows)
-  for (int idx = lane; idx < wsz; idx += 64) {
+  for (int idx = lane + 64 * wave; idx < wsz; idx += 64 * NWE) {
     const int r = idx / wl, t = idx - r * wl;
     win[idx] = (t <= bw) ? band_row_entry(Hb, ld, act, p, reg, r, t) : 0.0;
   }
-  // chunk c = raw rows R + c*ld .. of H; chunk c is consumed from buffer c & 1
-  fetch(Hb, R * ld, p * ld);
-  park(0);
-  fetch(Hb, (R + ld) * ld, p * ld);
-  park(1);
-  fetch(Hb, (R + 2 * ld) * ld, p * ld);
-  // this lane's duos: duo q in row-major order over rows s = 1 .. bw below the block (entries t = s, s+2, ...),
-  // q = lane + 64 u.  A lane past the end of the last round repeats a duo of the same round: two lanes then store
-  // the same bits to the same address (all loads of a step precede its stores), which needs no predicate.
+  // chunk c = raw rows R + c*CH .. of H; chunk c is consumed from buffer c & 1 (the wave that admits rows stages them)
+  if (wlast) {
+    fetch(Hb, R * ld, p * ld);
+    park(0);
+    fetch(Hb, (R + CH) * ld, p * ld);
+    park(1);
+    fetch(Hb, (R + 2 * CH) * ld, p * ld);
+  }
+  // this wave's duos: duo q in row-major order over rows s = 1 .. bw below the block (entries t = s, s+2, ...);
+  // round u = duos 64u .. 64u + 63, dealt to wave u % NWE.  A lane past the end of the last round repeats a duo of
+  // the same round: two lanes of one wave then store the same bits to the same address (all loads of a step precede
+  // its stores), which needs no predicate.
   int uq[U], up[U], ur[U];
   const int nd = band_wave_duos(bw);
   const int nu = (nd + 63) / 64;
+  const int nuw = nu > wave ? (nu - wave + NWE - 1) / NWE : 0;
   {
 #pragma unroll
     for (int i = 0; i < U; ++i) {
-      int nv = nd - 64 * i;
+      const int u = wave + NWE * i;
+      int nv = nd - 64 * u;
       nv = nv > 64 ? 64 : (nv < 1 ? 1 : nv);
-      int q = 64 * i + (lane < nv ? lane : lane % nv), s = 1;
+      int q = 64 * u + (lane < nv ? lane : lane % nv), s = 1;
       q = q < nd ? q : 0;
       while (q >= (bw - s + 2) / 2) { q -= (bw - s + 2) / 2; ++s; }
       const int t = s + 2 * q;
@@ -540,14 +563,57 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     }
   }
   // zero column of the scratch, written once
-  if (lane < NB) { scrP[NB * (ncol - 1) + lane] = 0.0; scrQ[NB * (ncol - 1) + lane] = 0.0; }
-  asm volatile("" ::: "memory");
+  if (w0 && lane < NB) { scrP[NB * (ncol - 1) + lane] = 0.0; scrQ[NB * (ncol - 1) + lane] = 0.0; }
+  bar();
   CAVE_ACC(10);
   auto eliminate = [&](auto nu_tag) __attribute__((always_inline)) {
     constexpr int NU = decltype(nu_tag)::value;
     int slot_k = 0, cidx = 0, cpos = 0;
     const bool zl = lane == 63;
+    // ---- E: rows kk + R .. kk + R + 3 take the slots (first: slot_e) of the four rows retired by step kk.  All loads first, from clamped
+      // addresses, and the masks as selects: written with an `if`, each row pays two dependent LDS round trips
+      // (the loads are sunk into the branch) -- measured at ~490 cycles per row, more than the elimination itself.
+    auto admit = [&](const int kk, const int slot_e) __attribute__((always_inline)) {
+        const int tl = lane <= bw ? lane : bw;
+        double raw[NB];
+        uint32_t fI[NB], fJ[NB];
+        int dst[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          int cp = cpos + a, cb = cidx;
+          if (cp >= CH) { cp -= CH; ++cb; }
+          int sl = slot_e + a;
+          sl = sl >= R ? sl - R : sl;
+          dst[a] = sl * wl + tl;
+          const int rI = kk + R + a;
+#ifdef CAVE_X_EGLOBAL
+          raw[a] = Hb[(rI < p ? rI : p - 1) * ld + tl];
+#else
+          raw[a] = stg[(cb & 1) * csz + cp * ld + tl];
+#endif
+          fI[a] = act[rI < p ? rI : p - 1];
+          fJ[a] = act[rI + tl < p ? rI + tl : p - 1];
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const int rI = kk + R + a;
+          const bool fixed = (fI[a] | fJ[a]) != 0u;
+          const double diag = fI[a] != 0u ? 1.0 : raw[a] + reg;
+          double v = (lane == 0) ? diag : (fixed ? 0.0 : raw[a]);
+          v = (rI + tl < p) ? v : 0.0;
+          if (lane <= bw) win[dst[a]] = v;
+        }
+        cpos += NB;
+        if (cpos >= CH) {  // into chunk cidx + 1: chunk cidx + 2 (registers) takes the buffer chunk cidx has left
+          cpos -= CH;
+          ++cidx;
+          park((cidx + 1) & 1);
+          fetch(Hb, (R + (cidx + 2) * CH) * ld, p * ld);
+        }
+      };
     for (int k = 0; k < p; k += NB) {
+      double zq[NB] = {0.0, 0.0, 0.0, 0.0};
+      if (w0) {
       // ---- A: pivot rows k .. k+3 into registers; lane t holds column k + t (entry t - a of row k + a)
       double u[NB];
 #pragma unroll
@@ -583,7 +649,6 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
           scrQ[NB * lane + a] = u[a] * inv[a];
         }
       }
-      double zq[NB];
 #pragma unroll
       for (int a = 0; a < NB; ++a) {
         zq[a] = readlane_f64(u[a], 63);
@@ -595,8 +660,18 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         for (int a = 0; a < NB; ++a)
           if (k + a < p) z[k + a] = u[a];
       }
-      asm volatile("" ::: "memory");
+      }  // w0
+      if constexpr (NWE > 1) {
+        if (!w0 && k > 0) admit(k - NB, slot_k >= NB ? slot_k - NB : slot_k - NB + R);
+      }
+      bar();
       CAVE_ACCF(1);
+      if constexpr (NWE > 1) {
+        if (!w0) {  // the right-hand side entries wave 0 has just finished
+#pragma unroll
+          for (int a = 0; a < NB; ++a) zq[a] = z[k + a < p ? k + a : p - 1];
+        }
+      }
       // ---- C: trailing triangle
       const int base_k = slot_k * wl;
       double qv[NU > 0 ? NU : 1][NB], p0[NU > 0 ? NU : 1][NB], p1[NU > 0 ? NU : 1][NB], r0[NU > 0 ? NU : 1], r1[NU > 0 ? NU : 1];
@@ -616,7 +691,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         r1[i] = win[o + 1];
       }
       // ---- D: right-hand side below the block (lane i: row k + NB + i)
-      const bool zown = lane < bw && k + NB + lane < p;
+      const bool zown = wlast && lane < bw && k + NB + lane < p;
       double zqv[NB];
 #pragma unroll
       for (int a = 0; a < NB; ++a) zqv[a] = scrQ[NB * (NB + (lane < bw ? lane : 0)) + a];
@@ -635,50 +710,14 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       for (int a = 0; a < NB; ++a) zz = fma(-zqv[a], zq[a], zz);
       if (zown) z[k + NB + lane] = zz;
       CAVE_ACCF(9);
-      // ---- E: rows k + R .. k + R + 3 take the slots of the four retired ones.  All loads first, from clamped
-      // addresses, and the masks as selects: written with an `if`, each row pays two dependent LDS round trips
-      // (the loads are sunk into the branch) -- measured at ~490 cycles per row, more than the elimination itself.
-      {
-        const int tl = lane <= bw ? lane : bw;
-        double raw[NB];
-        uint32_t fI[NB], fJ[NB];
-        int dst[NB];
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-          int cp = cpos + a, cb = cidx;
-          if (cp >= ld) { cp -= ld; ++cb; }
-          int sl = slot_k + a;
-          sl = sl >= R ? sl - R : sl;
-          dst[a] = sl * wl + tl;
-          const int rI = k + R + a;
-          raw[a] = stg[(cb & 1) * csz + cp * ld + tl];
-          fI[a] = act[rI < p ? rI : p - 1];
-          fJ[a] = act[rI + tl < p ? rI + tl : p - 1];
-        }
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-          const int rI = k + R + a;
-          const bool fixed = (fI[a] | fJ[a]) != 0u;
-          const double diag = fI[a] != 0u ? 1.0 : raw[a] + reg;
-          double v = (lane == 0) ? diag : (fixed ? 0.0 : raw[a]);
-          v = (rI + tl < p) ? v : 0.0;
-          if (lane <= bw) win[dst[a]] = v;
-        }
-        cpos += NB;
-        if (cpos >= ld) {  // into chunk cidx + 1: chunk cidx + 2 (registers) takes the buffer chunk cidx has left
-          cpos -= ld;
-          ++cidx;
-          park((cidx + 1) & 1);
-          fetch(Hb, (R + (cidx + 2) * ld) * ld, p * ld);
-        }
-      }
+      if constexpr (NWE == 1) admit(k, slot_k);
       slot_k += NB;
       slot_k = slot_k >= R ? slot_k - R : slot_k;
-      asm volatile("" ::: "memory");
+      bar();
       CAVE_ACCF(11);
     }
   };
-  switch (nu) {
+  switch (nuw) {
     case 0: eliminate(std::integral_constant<int, 0>{}); break;
     case 1: eliminate(std::integral_constant<int, 1>{}); break;
     case 2: eliminate(std::integral_constant<int, 2>{}); break;
@@ -686,6 +725,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     case 4: eliminate(std::integral_constant<int, 4>{}); break;
     default: eliminate(std::integral_constant<int, 5>{}); break;
   }
+  if (!w0) return;
   // the factor rows go out through this wave's stores and come back through its loads
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -740,7 +780,11 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     auto entry = [&](int r, int t) -> double { return ring[t <= bw ? (r & 63) * rs + t : zero_at]; };
     int k = p - 1;
     // the p mod NB rows at the bottom, one at a time
+#ifdef CAVE_X_BACK1
+    for (; k >= 0; --k) {
+#else
     for (; k >= 0 && ((k + 1) % NB) != 0; --k) {
+#endif
       admit(k);
       const int sft = 1 + ((k - 1 - lane) & 63);
       const double fcol = ring[sft < ld ? rowbase + sft : zero_at];

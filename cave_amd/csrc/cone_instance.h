@@ -170,7 +170,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.ldh = (int)ld;
       // narrow bands: the whole elimination runs on one wave (cone_band.h, solve_spd_band_wave)
       bool wave_mode = false;
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(CAVE_NO_BAND_WAVE)  // (diagnostic builds can pin the team form of the band solver)
       if constexpr (C::WL == 64) {
         const uint64_t need = 8ull * (band_wave_window(bw) + 2ull * pp + band_wave_staging(bw, p)) + pp + 64u;
         wave_mode = hot != nullptr && band_wave_fits(bw, p) && (uint64_t)(hot->top - hot->off) >= need;

@@ -348,3 +348,53 @@ def test_prepared_form_pipelines_pack_and_solve(golden):
     assert bool((got["status"] == 0).all()) and torch.equal(got["proj"], ref["proj"])
     assert prepare_dense(bt) is bt  # the shape is now known not to fit: prepare declines
     qpsolver.forget_shape(*key)
+
+
+def _banded_inequality_cones(B, m, width, shift, seed, pairs=0):
+    """General (>=) rows whose supports slide along the cost vector: M M^T is a narrow band, the reduced rows
+    carry theta >= 0 multipliers, so the active-set inner loop fixes rows (identity rows in the band solver);
+    `pairs` rows are duplicated with the opposite sign (+a / -a pairs: free multipliers)."""
+    rng = np.random.default_rng(seed)
+    d = shift * (m - 1) + width
+    A = np.zeros((B, m + pairs, d), np.float32)
+    for i in range(m):
+        A[:, i, i * shift:i * shift + width] = rng.standard_normal((B, width)).astype(np.float32)
+    for j in range(pairs):
+        A[:, m + j] = -A[:, (j * 7) % m]
+    y = rng.standard_normal((B, d)).astype(np.float32)
+    return A, y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,width,shift,pairs", [(90, 3, 1, 0), (130, 6, 2, 5), (200, 4, 1, 9), (90, 5, 1, 0), (131, 9, 2, 7), (91, 6, 1, 0), (70, 40, 3, 0), (67, 2, 1, 3)])
+def test_band_solver_with_bound_rows_vs_oracle(m, width, shift, pairs):
+    """The one-wave band elimination (cone_band.h) with rows held at their bound: banded cones of inequality rows
+    (half bandwidths 1 .. 13 -- below 3 the team form of the solver runs --, more than 64 reduced rows, row counts not a multiple of the block of four), dense
+    operator and packed store at 4-, 2- and 1-wave workgroups, against the CPU oracle."""
+    import os
+
+    import torch
+
+    from cave_amd.qpsolver import cone_op_dense
+    from cave_amd.dataset import ConeStore
+    from oracle import cave_oracle as O
+
+    A, y = _banded_inequality_cones(6, m, width, shift, seed=m + width, pairs=pairs)
+    po, ro = O.batch_project(y, A)
+    tol = 4e-6 * max(1.0, float(np.abs(y).max()))
+    At, yt = torch.tensor(A, device="cuda"), torch.tensor(y, device="cuda")
+    o = cone_op_dense(At, yt, 0, 1.0, 0.0)
+    assert (o["status"].cpu().numpy() == 0).all()
+    assert np.abs(o["proj"].cpu().numpy() - po).max() <= tol and np.abs(o["rnorm"].cpu().numpy() - ro).max() <= tol
+    st = ConeStore.from_dense(At, chunk=6)
+    assert st.large
+    ids = torch.arange(6, device="cuda")
+    for waves in ("4", "2", "1"):
+        os.environ["CAVE_LARGE_WAVES"] = waves
+        try:
+            q = st.cone_op(ids, yt, 0, 1.0, outputs=("proj", "rnorm"))
+        finally:
+            os.environ.pop("CAVE_LARGE_WAVES", None)
+        assert (q["status"].cpu().numpy() == 0).all(), waves
+        assert np.abs(q["proj"].cpu().numpy() - po).max() <= tol, waves
+        assert np.abs(q["rnorm"].cpu().numpy() - ro).max() <= tol, waves

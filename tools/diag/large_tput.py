@@ -2,7 +2,8 @@
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
-from cave_amd import synth
+from cave_amd import synth, _lib
+if os.environ.get('CAVE_SO'): _lib.LIB_PATH = os.path.abspath(os.environ['CAVE_SO'])
 from cave_amd.dataset import ConeStore
 
 def timed(fn, n=3):
@@ -22,6 +23,7 @@ print(f"{which}: pack {nuniq} instances {time.time()-t0:.2f}s; store {st.nbytes(
 del c
 if os.environ.get("LDS"): st.large_lds = int(os.environ["LDS"])
 for B in Bs:
+    torch.manual_seed(1234 + B)
     ids = torch.arange(B, device=dev) % nuniq
     p = p0[ids] + 0.01 * torch.randn(B, p0.shape[1], device=dev)
     o = st.cone_op(ids, p, 2, -1.0, outputs=("loss", "grad"))
