@@ -397,8 +397,11 @@ CAVE_HOSTDEV uint32_t band_wave_scratch(int bw) { return 2u * (uint32_t)kBandBlo
 // staging entries: two chunks of bw + 1 raw rows on the way down, a 64-row ring of factor rows on the way back.  The
 // scratch lives in x (unused until the back substitution) when p is large enough, else behind the staging chunks.
 CAVE_HOSTDEV int band_wave_chunk(int bw) { return bw + 1 < 2 * kBandBlock ? 2 * kBandBlock : bw + 1; }  // rows per staged chunk
+// row stride of the factor ring of the back substitution (an even stride would spread the per-lane reads over all
+// banks -- 31 gives 4-way conflicts -- but measured no faster on the 30x30 batch, and costs LDS)
+CAVE_HOSTDEV int band_wave_ring_stride(int bw) { return bw + 1; }
 CAVE_HOSTDEV uint32_t band_wave_staging(int bw, int p) {
-  const uint32_t ld = (uint32_t)bw + 1u, b = 64u * ld + 1u;
+  const uint32_t ld = (uint32_t)bw + 1u, b = 64u * (uint32_t)band_wave_ring_stride(bw) + 1u;
   uint32_t a = 2u * (uint32_t)band_wave_chunk(bw) * ld;
   if ((uint32_t)p < band_wave_scratch(bw)) a += band_wave_scratch(bw);
   return a > b ? a : b;
@@ -437,10 +440,10 @@ __device__ __forceinline__ T* uniform_ptr(T* q) {  // arguments of a real call a
 // The elimination advances kBandBlock = 4 pivots per step:
 //   A  the four pivot rows are read into registers (lane t = column k + t, lane 63 = the right-hand side) and
 //      eliminated against each other there (v_readlane broadcasts, no LDS traffic);
-//   B  pivot rows P[t][0..3] and multipliers Q[t][0..3] = P * (1/d) go to an LDS scratch as 32-byte records, the
-//      finished rows to the factor (workspace);
-//   C  every duo of the trailing triangle takes its four updates in one pass: 2 + 4 ds_read_b128 of operands whose
-//      addresses never change, one ds_read2_b64 / ds_write2_b64 of the target -- a quarter of the LDS round trips and
+//   B  pivot rows P[0..3][t] and multipliers Q[0..3][t] = P * (1/d) go to an LDS scratch, the finished rows to the
+//      factor (workspace);
+//   C  every duo of the trailing triangle takes its four updates in one pass: 4 + 4 operand reads whose addresses
+//      never change, one ds_read2_b64 / ds_write2_b64 of the target -- a quarter of the LDS round trips and
 //      of the address arithmetic of a pivot-at-a-time loop (measured on a 30x30 grid: ~1190 cycles per pivot there,
 //      issue- and latency-bound at ~130 instructions per pivot on a lone wave);
 //   D  the right-hand side below the block; E  four new rows take the slots of the four retired ones.
@@ -487,7 +490,9 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   auto z = space_cast<3>(z_);
   auto x = space_cast<3>(x_);
   auto stg = space_cast<3>(stg_);
-  // operand scratch: P[t][a] = U[k+a][k+t], Q[t][a] = P[t][a] / d_a, t = NB .. bw + NB + 1 (last column: zeros)
+  // operand scratch: P[a][t] = U[k+a][k+t], Q[a][t] = P[a][t] / d_a, t = NB .. bw + NB + 1 (last column: zeros).
+  // Component-major: the lanes of a duo round read consecutive t, i.e. consecutive words (as [t][a] records the
+  // same reads were 16-way bank conflicts: rocprof counted 1.0e9 conflict cycles per launch on the 30x30 batch)
   const int ncol = bw + NB + 2;
   auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : stg + 2 * csz;  // (csz = one staged chunk)
   auto scrQ = scrP + NB * ncol;
@@ -557,13 +562,13 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       q = q < nd ? q : 0;
       while (q >= (bw - s + 2) / 2) { q -= (bw - s + 2) / 2; ++s; }
       const int t = s + 2 * q;
-      uq[i] = NB * (s + NB - 1);        // record of column k + NB - 1 + s in Q
-      up[i] = NB * (t + NB - 1);        // ... of column k + NB - 1 + t (and the next one) in P
+      uq[i] = s + NB - 1;               // column k + NB - 1 + s in Q
+      up[i] = t + NB - 1;               // column k + NB - 1 + t (and the next one) in P
       ur[i] = (s + NB - 1) * wl + (t - s);  // target, relative to the first pivot row's slot
     }
   }
   // zero column of the scratch, written once
-  if (w0 && lane < NB) { scrP[NB * (ncol - 1) + lane] = 0.0; scrQ[NB * (ncol - 1) + lane] = 0.0; }
+  if (w0 && lane < NB) { scrP[lane * ncol + ncol - 1] = 0.0; scrQ[lane * ncol + ncol - 1] = 0.0; }
   bar();
   CAVE_ACC(10);
   auto eliminate = [&](auto nu_tag) __attribute__((always_inline)) {
@@ -645,8 +650,8 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       if (lane >= NB && lane < ncol - 1) {
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
-          scrP[NB * lane + a] = u[a];
-          scrQ[NB * lane + a] = u[a] * inv[a];
+          scrP[a * ncol + lane] = u[a];
+          scrQ[a * ncol + lane] = u[a] * inv[a];
         }
       }
 #pragma unroll
@@ -683,9 +688,9 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         poff[i] = o;
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
-          qv[i][a] = scrQ[uq[i] + a];
-          p0[i][a] = scrP[up[i] + a];
-          p1[i][a] = scrP[up[i] + NB + a];
+          qv[i][a] = scrQ[a * ncol + uq[i]];
+          p0[i][a] = scrP[a * ncol + up[i]];
+          p1[i][a] = scrP[a * ncol + up[i] + 1];
         }
         r0[i] = win[o];
         r1[i] = win[o + 1];
@@ -694,7 +699,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       const bool zown = wlast && lane < bw && k + NB + lane < p;
       double zqv[NB];
 #pragma unroll
-      for (int a = 0; a < NB; ++a) zqv[a] = scrQ[NB * (NB + (lane < bw ? lane : 0)) + a];
+      for (int a = 0; a < NB; ++a) zqv[a] = scrQ[a * ncol + NB + (lane < bw ? lane : 0)];
       double zz = z[zown ? k + NB + lane : 0];
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
@@ -735,11 +740,11 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
 #endif
   // ---- back substitution  x_k = inv_k (z_k - sum_s U[k][k+s] x_{k+s}), column oriented.
   // Factor rows come back through a 64-row ring in LDS (row r in slot r & 63; one zero entry behind the ring), so lane l
-  // finds every row it owns at l * ld: the entry of column k in its row is at offset s = k - row, and an offset past
+  // finds every row it owns at l * stride: the entry of column k in its row is at offset s = k - row, and an offset past
   // the band is redirected to the zero entry.  Rows are fetched CHB at a time (registers: lane = entry,
   // register = row), a chunk ahead, and parked once the rows that used their slots are done.
   constexpr int CHB = RMAX;
-  const int rs = ld, zero_at = 64 * ld;
+  const int rs = band_wave_ring_stride(bw), zero_at = 64 * rs;
   auto ring = stg;
   ring[zero_at] = 0.0;
   const int tl = lane < ld ? lane : bw;

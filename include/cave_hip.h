@@ -183,11 +183,13 @@ int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, 
 
 /* ------------------------------------------------------------------ large-cone path
  * Same operators, same per-instance semantics and outputs, for cones beyond the fast path's limits
- * (more than 64 reduced rows, or more non-zeros than 160 KiB of LDS holds).  Persistent 4-wave
- * workgroups; each works in its own slice of a caller-owned, 16-byte aligned device `workspace` of
+ * (more than 64 reduced rows, or more non-zeros than 160 KiB of LDS holds).  Persistent workgroups
+ * (4 waves; cave_hip_cone_packed_large takes 2-wave workgroups when the batch needs more than two
+ * workgroups per CU and four fit the LDS); each works in its own slice of a caller-owned, 16-byte aligned device `workspace` of
  * n_slots * slice_bytes bytes (n_slots = number of workgroups launched, at most B are used; a few per
  * CU is enough).  The Newton systems are kept as symmetric bands (band = reduced rows x (half
- * bandwidth + 1) entries) and solved by an LDL^T band elimination.  An instance that does not fit its
+ * bandwidth + 1) entries) and solved by an LDL^T band elimination (narrow bands -- half bandwidth
+ * 4 .. 34, grid shortest-path cones -- four pivots per step on one or two waves).  An instance that does not fit its
  * slice reports CAVE_ST_TOO_LARGE: retry with a larger slice.
  *   nnz_cap       non-zeros kept per instance
  *   band_entries  expected rows x (bandwidth + 1) of the reduced system (sizing hint)

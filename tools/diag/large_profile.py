@@ -15,6 +15,7 @@ items, costs, _ = synth.coo_batch(kind, size, B, seed=0)
 d = costs.shape[1]; m_max = max(it[3] for it in items)
 store = ConeStore.from_chunks_lazy(lambda i: synth.densify_on(items[i:i + chunk], d, dev, m_max), list(range(0, B, chunk)))
 ids = torch.arange(B, device=dev)
+torch.manual_seed(0)
 pred = torch.tensor(costs, device=dev) + 0.05 * torch.randn(B, d, device=dev)
 o = store.cone_op(ids, pred, _lib.MODE_INNER, -1.0, 0.2, outputs=("loss", "grad"))
 torch.cuda.synchronize()
