@@ -46,6 +46,12 @@ def test_default_limits_and_arg_validation():
     assert 0 < s1 < lib.cave_hip_large_slice_bytes(5155, 4950, 80000, 16000) < lib.cave_hip_large_slice_bytes(5155, 4950, 80000, 64000)
     assert lib.cave_hip_large_slice_bytes(5155, 0, 40000, 16000) == -1
     assert 0 < lib.cave_hip_packed_large_slice_bytes(1740, 900, 27900) < 1 << 20
+    # v7: exact LDS of the band solver's hot arrays -- a narrow band (30x30 grid: 900 rows, half bandwidth 30) must
+    # leave room for four workgroups per CU, a dense reduced system (TSP-100) takes most of the CU's LDS
+    grid = lib.cave_hip_packed_large_lds_bytes(900, 30)
+    assert 0 < grid and 4 * grid <= 160 * 1024
+    assert 80 * 1024 < lib.cave_hip_packed_large_lds_bytes(105, 104) <= 160 * 1024
+    assert lib.cave_hip_packed_large_lds_bytes(-1, 3) < 0
     none8 = [None] * 8
     assert lib.cave_hip_cone_dense_large(None, None, 1, 4, 4, 0, 1.0, 0.0, 0, 64, 0, None, 1 << 20, 4, *none8) == -1  # null pointers
     assert lib.cave_hip_cone_dense_large(None, None, 1, 70000, 4, 0, 1.0, 0.0, 0, 64, 0, None, 1 << 20, 4, *none8) == -1
