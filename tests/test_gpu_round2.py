@@ -398,3 +398,32 @@ def test_band_solver_with_bound_rows_vs_oracle(m, width, shift, pairs):
         assert (q["status"].cpu().numpy() == 0).all(), waves
         assert np.abs(q["proj"].cpu().numpy() - po).max() <= tol, waves
         assert np.abs(q["rnorm"].cpu().numpy() - ro).max() <= tol, waves
+
+
+def test_warm_start_on_the_large_cone_path():
+    """The multiplier cache also serves cones on the large path (12x12 grid: 144 reduced rows, band solver): same
+    projections as a cold start, fewer Newton iterations once the predictions only drift."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+
+    c, y, _ = synth.sp_batch(12, 12, 48, seed=4)
+    st = ConeStore.from_dense(torch.tensor(c, device="cuda"), chunk=48)
+    assert st.large
+    ids = torch.arange(48, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    p = torch.tensor(y, device="cuda") + torch.tensor(0.05 * torch.randn(y.shape, generator=g).numpy(), device="cuda")
+    cold = st.cone_op(ids, p, 2, -1.0, outputs=ALL)
+    st.enable_warm_start()
+    st.cone_op(ids, p, 2, -1.0, outputs=ALL)
+    p2 = p + torch.tensor(0.01 * torch.randn(y.shape, generator=g).numpy(), device="cuda")
+    warm = st.cone_op(ids, p2, 2, -1.0, outputs=ALL)
+    st.enable_warm_start(False)
+    ref = st.cone_op(ids, p2, 2, -1.0, outputs=ALL)
+    assert bool((warm["status"] == 0).all())
+    scale = max(1.0, float(p2.abs().max()))
+    for k in ("proj", "loss", "grad"):
+        assert float((warm[k] - ref[k]).abs().max()) <= 4e-6 * scale, k
+    assert float(warm["iters"].float().mean()) <= float(ref["iters"].float().mean()) - 1.0
+    assert float(cold["iters"].float().mean()) >= float(warm["iters"].float().mean()) + 1.0
