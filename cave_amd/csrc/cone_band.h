@@ -591,11 +591,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
           sl = sl >= R ? sl - R : sl;
           dst[a] = sl * wl + tl;
           const int rI = kk + R + a;
-#ifdef CAVE_X_EGLOBAL
-          raw[a] = Hb[(rI < p ? rI : p - 1) * ld + tl];
-#else
           raw[a] = stg[(cb & 1) * csz + cp * ld + tl];
-#endif
           fI[a] = act[rI < p ? rI : p - 1];
           fJ[a] = act[rI + tl < p ? rI + tl : p - 1];
         }
@@ -785,11 +781,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     auto entry = [&](int r, int t) -> double { return ring[t <= bw ? (r & 63) * rs + t : zero_at]; };
     int k = p - 1;
     // the p mod NB rows at the bottom, one at a time
-#ifdef CAVE_X_BACK1
-    for (; k >= 0; --k) {
-#else
     for (; k >= 0 && ((k + 1) % NB) != 0; --k) {
-#endif
       admit(k);
       const int sft = 1 + ((k - 1 - lane) & 63);
       const double fcol = ring[sft < ld ? rowbase + sft : zero_at];
