@@ -272,6 +272,99 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     // LDS accesses, no per-pair index arithmetic; the factor is copied out in one pass at the end.
     constexpr int TX = NT >= 64 ? 32 : 1, TY = NT / TX;
     const int tx = tid % TX, ty = tid / TX;
+    bool blocked = false;
+#if defined(__HIPCC__)
+    if constexpr (HOT && C::WL == 64) blocked = p <= 127 && 2 * CH * ld >= 8 * (p + 2);
+    if constexpr (HOT && C::WL == 64) if (blocked) {
+      // Four pivots per step, as in solve_spd_band_wave below: wave 0 eliminates the four pivot rows against each
+      // other in registers (lane = column, two columns per lane: p <= 127) and publishes them and the multipliers
+      // (component-major scratch in the idle staging buffers); after one barrier every wave takes whole trailing
+      // rows, two adjacent entries per lane, four updates per entry from operands whose addresses it never has to
+      // recompute.  One barrier pair per FOUR pivots and no dependent LDS round trip per entry (the row-at-a-time
+      // loop below: ~4500 cycles per pivot on TSP-100).  Same fma sequence per entry: same bits.
+      constexpr int NBD = 4, NWV = NT / 64;
+      const int pc = p + 2;
+      auto scP = stg, scQ = stg + NBD * pc;
+      for (int k0 = 0; k0 < p; k0 += NBD) {
+        if (wave == 0) {
+          double u[NBD][2], zv[NBD], inv[NBD];
+#pragma unroll
+          for (int a = 0; a < NBD; ++a) {
+            const int row = k0 + a;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int col = k0 + lane + 64 * g, off = col - row;
+              const bool in = row < p && off >= 0 && col < p;
+              const double v = win[in ? row * ld + off : 0];
+              u[a][g] = in ? v : 0.0;
+            }
+            const double zr = z[row < p ? row : p - 1];
+            zv[a] = row < p ? zr : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < NBD; ++a) {
+            const double d = readlane_f64(u[a][0], a);
+            const double iv = (d > 1e-300) ? 1.0 / d : 0.0;
+            inv[a] = iv;
+#pragma unroll
+            for (int b = a + 1; b < NBD; ++b) {
+              const double m = readlane_f64(u[a][0], b) * iv;
+              u[b][0] = fma(-m, u[a][0], u[b][0]);
+              u[b][1] = fma(-m, u[a][1], u[b][1]);
+              zv[b] = fma(-m, zv[a], zv[b]);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int t = lane + 64 * g;  // column k0 + t; t = p - k0 is the zero column
+            if (t >= NBD && t <= p - k0) {
+#pragma unroll
+              for (int a = 0; a < NBD; ++a) {
+                scP[a * pc + t] = u[a][g];
+                scQ[a * pc + t] = u[a][g] * inv[a];
+              }
+            }
+#pragma unroll
+            for (int a = 1; a < NBD; ++a) {  // rows k0+1 .. k0+3 as the later pivots have left them
+              const int row = k0 + a, off = k0 + t - row;
+              if (row < p && off >= 0 && k0 + t < p) win[row * ld + off] = u[a][g];
+            }
+          }
+          if (lane < NBD && k0 + lane < p) z[k0 + lane] = lane == 0 ? zv[0] : (lane == 1 ? zv[1] : (lane == 2 ? zv[2] : zv[3]));
+        }
+        c.sync_lds();
+        for (int r = k0 + NBD + wave; r < p; r += NWV) {
+          const int tr = r - k0, c0 = r + 2 * lane;
+          if (c0 < p) {
+            const int o = r * ld + 2 * lane, t0 = c0 - k0;
+            double q[NBD], p0[NBD], p1[NBD];
+#pragma unroll
+            for (int a = 0; a < NBD; ++a) {
+              q[a] = scQ[a * pc + tr];
+              p0[a] = scP[a * pc + t0];
+              p1[a] = scP[a * pc + t0 + 1];
+            }
+            double r0 = win[o], r1 = win[o + 1];
+#pragma unroll
+            for (int a = 0; a < NBD; ++a) {
+              r0 = fma(-q[a], p0[a], r0);
+              r1 = fma(-q[a], p1[a], r1);
+            }
+            win[o] = r0;
+            win[o + 1] = r1;
+          }
+        }
+        for (int r = k0 + NBD + tid; r < p; r += NT) {
+          double zz = z[r];
+#pragma unroll
+          for (int a = 0; a < NBD; ++a) zz = fma(-scQ[a * pc + (r - k0)], z[k0 + a < p ? k0 + a : p - 1], zz);
+          z[r] = zz;
+        }
+        c.sync_lds();
+      }
+    }
+#endif
+    if (!blocked)
     for (int k = 0; k < p; ++k) {
       auto wk = win + k * ld;
       const double dk = wk[0];

@@ -23,6 +23,8 @@ buf = (C.c_ulonglong * (16 * B))()
 lib.cave_hip_debug_stamps(buf, B)
 a = np.frombuffer(buf, dtype=np.uint64).reshape(B, 16).astype(np.float64)
 mean = a.mean(0); tot = mean[14]
+rt = a[:, 15] / 100.0
+print("per-instance time (us) quantiles 0/50/90/99/100:", [round(float(np.quantile(rt, q))) for q in (0, .5, .9, .99, 1)], "slowest instances:", np.argsort(rt)[-5:].tolist(), "their iters", o["iters"].cpu().numpy()[np.argsort(rt)[-5:]].tolist())
 print(f"{which} B={B}: iters mean {o['iters'].float().mean():.2f}; cycles/instance {tot:.0f} = {mean[15]/100:.1f} us")
 if "fine" in os.environ.get("STAMPS_SO", ""):
     print(f"  per pivot (fine stamps): block A {mean[0]/mean[13]:.0f}  B {mean[1]/mean[13]:.0f}  C+D {mean[9]/mean[13]:.0f}  E {mean[11]/mean[13]:.0f}")
