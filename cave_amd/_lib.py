@@ -16,11 +16,16 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libcave_hip.so")
-_SOURCES = [
-    os.path.join(_HERE, "csrc", n)
-    for n in ("cave_hip.hip", "cone_common.h", "cone_core.h", "cone_band.h", "cone_instance.h", "wave_prims.h",
-              "ctx_wave.h", "ctx_block.h")
-] + [os.path.join(_ROOT, "include", "cave_hip.h")]
+_CSRC = os.path.join(_HERE, "csrc")
+_HEADERS = [os.path.join(_CSRC, n) for n in ("kernels.h", "cone_common.h", "cone_core.h", "cone_band.h", "cone_instance.h",
+                                             "wave_prims.h", "ctx_wave.h", "ctx_block.h")] + \
+    [os.path.join(_ROOT, "include", "cave_hip.h")]
+# translation units: the C ABI (host code) + one file per kernel shape (cave_amd/csrc/kernels.h)
+_UNITS = ["cave_hip"] + [f"k_{op}_w{w}" for op in ("dense", "pack", "packed") for w in (1, 2, 4, 8)] + \
+    ["k_large_dense", "k_large_pack", "k_large_packed_w1", "k_large_packed_w2", "k_large_packed_w4"]
+_SOURCES = [os.path.join(_CSRC, u + ".hip") for u in _UNITS] + _HEADERS
+_OBJ_DIR = os.path.join(_CSRC, "build")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC"]
 
 # status / mode constants (include/cave_hip.h)
 ST_OK, ST_NOT_CONVERGED, ST_TOO_LARGE, ST_BAD_INPUT = 0, 1, 2, 3
@@ -36,17 +41,39 @@ ABI_SYMBOLS = (
 )
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> cave_amd/libcave_hip.so (in-tree; cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in _SOURCES)
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """hipcc --offload-arch=gfx950 -> cave_amd/libcave_hip.so (in-tree; cross-compiles without a GPU).
+
+    Every kernel shape is its own translation unit (objects under cave_amd/csrc/build/): they compile in
+    parallel and only the units older than their sources are rebuilt."""
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
-           _SOURCES[0], "-o", LIB_PATH]
+    os.makedirs(_OBJ_DIR, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(p) for p in _HEADERS)
+    todo, objs = [], []
+    for u in _UNITS:
+        src, obj = os.path.join(_CSRC, u + ".hip"), os.path.join(_OBJ_DIR, u + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_hdr, os.path.getmtime(src)):
+            todo.append((src, obj))
+    if not todo and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs is None:
+        jobs = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4, 8))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB_PATH
 
@@ -105,7 +132,7 @@ def load_library() -> C.CDLL:
     lib.cave_hip_cone_dense_large.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i64, i32, vp, i64, i32,
                                               vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cave_hip_pack_large.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, vp, vp, C.POINTER(Store), i64, vp, vp]
-    lib.cave_hip_cone_packed_large.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32, vp, i64, i32,
+    lib.cave_hip_cone_packed_large.argtypes = [C.POINTER(Store), vp, vp, i64, i32, f32, f32, i32, i32, i32, vp, i64, i32,
                                                vp, vp, vp, vp, vp, vp, vp, vp]
     for name in ("cave_hip_cone_dense_large", "cave_hip_pack_large", "cave_hip_cone_packed_large"):
         getattr(lib, name).restype = C.c_int32

@@ -187,6 +187,7 @@ class ConeStore:
         self.warm_start = False
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
         self.waves = 0  # 0 = choose per call
+        self.large_waves = 0  # large-cone path: waves per workgroup (1, 2, 4; 0 = the library's choice)
         self.all_pm1 = bool((t["flags"] & 1).all()) if N else False
         # every instance qualifies for the one-wave lite solver (cone_core.h: +-1 entries, <= 32 reduced rows,
         # <= 1024 non-zeros, d <= 256; columns with more than 8 entries fall back inside the kernel)
@@ -292,7 +293,7 @@ class ConeStore:
                 ws = _lib.workspace(dev, slots * slice_bytes)
                 rc = lib.cave_hip_cone_packed_large(
                     C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                    int(max_iter), self.large_lds, _lib.ptr(ws), slice_bytes, slots,
+                    int(max_iter), self.large_lds, int(self.large_waves), _lib.ptr(ws), slice_bytes, slots,
                     _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 7
+#define CAVE_HIP_ABI_VERSION 8
 
 /* return codes */
 #define CAVE_OK 0
@@ -214,12 +214,15 @@ int32_t cave_hip_pack_large(const float* ctrs, int64_t B, int64_t m_max, int64_t
                             int64_t slice_bytes, int32_t n_slots, int32_t* n_rows, int32_t* n_nnz,
                             const cave_cone_store* store, int64_t slot0, int32_t* status, void* stream);
 
-/* reads the cones in place from the store; the workspace only holds the solver's work arrays */
+/* reads the cones in place from the store; the workspace only holds the solver's work arrays.
+ *   waves (v8)  wavefronts per workgroup: 1, 2 or 4; 0 = library default (4, or 2 when the batch needs more than
+ *               two workgroups per compute unit and four workgroups fit the LDS).  The library reads no
+ *               environment variable and keeps no state between calls. */
 int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* ids, const float* pred, int64_t B,
                                    int32_t mode, float sign, float inner_ratio, int32_t max_iter, int32_t lds_bytes,
-                                   void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj, float* rnorm,
-                                   float* target, float* loss, float* grad, int32_t* status, int32_t* iters,
-                                   void* stream);
+                                   int32_t waves, void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj,
+                                   float* rnorm, float* target, float* loss, float* grad, int32_t* status,
+                                   int32_t* iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cave_hip_version() == 7
+    assert lib.cave_hip_version() == 8
     assert lib.cave_hip_device_count() >= 0
     assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
 
@@ -58,7 +58,7 @@ def test_default_limits_and_arg_validation():
     assert b"bad shape" in lib.cave_hip_last_error()
     assert lib.cave_hip_cone_dense_large(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 64, 0, None, 0, 0, *none8) == 0  # B == 0
     assert lib.cave_hip_pack_large(None, 1, 4, 4, 64, None, 1 << 20, 4, None, None, None, 0, None, None) == -1
-    assert lib.cave_hip_cone_packed_large(None, None, None, 1, 0, 1.0, 0.0, 0, 0, None, 1 << 20, 4, *none8) == -1
+    assert lib.cave_hip_cone_packed_large(None, None, None, 1, 0, 1.0, 0.0, 0, 0, 0, None, 1 << 20, 4, *none8) == -1
 
 
 def test_status_codes_match_header():

@@ -389,12 +389,9 @@ def test_band_solver_with_bound_rows_vs_oracle(m, width, shift, pairs):
     st = ConeStore.from_dense(At, chunk=6)
     assert st.large
     ids = torch.arange(6, device="cuda")
-    for waves in ("4", "2", "1"):
-        os.environ["CAVE_LARGE_WAVES"] = waves
-        try:
-            q = st.cone_op(ids, yt, 0, 1.0, outputs=("proj", "rnorm"))
-        finally:
-            os.environ.pop("CAVE_LARGE_WAVES", None)
+    for waves in (4, 2, 1):
+        st.large_waves = waves  # ABI v8: the workgroup shape is an argument of cave_hip_cone_packed_large
+        q = st.cone_op(ids, yt, 0, 1.0, outputs=("proj", "rnorm"))
         assert (q["status"].cpu().numpy() == 0).all(), waves
         assert np.abs(q["proj"].cpu().numpy() - po).max() <= tol, waves
         assert np.abs(q["rnorm"].cpu().numpy() - ro).max() <= tol, waves

@@ -14,8 +14,8 @@ for (m, width, shift, pairs) in [(200, 4, 1, 9), (200, 4, 1, 0), (90, 5, 1, 0), 
     st = ConeStore.from_dense(torch.tensor(A, device="cuda"), chunk=6)
     for lds in (st.large_lds, 65536):
         st.large_lds = lds
-        for w in ("4", "2", "1"):
-            os.environ["CAVE_LARGE_WAVES"] = w
+        for w in (4, 2, 1):
+            st.large_waves = w
             o = st.cone_op(torch.arange(6, device="cuda"), torch.tensor(y, device="cuda"), 0, 1.0, check=False, outputs=("proj", "rnorm"))
             print((m, width, shift, pairs), "rows", st.max_rows, "bw", st.max_bw, "lds", lds, "waves", w, "status", o["status"].cpu().numpy().tolist(),
                   "iters", o["iters"].cpu().numpy().tolist(), "err %.2e" % np.abs(o["proj"].cpu().numpy() - po).max(), flush=True)
