@@ -41,7 +41,9 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tsp", type=int, default=20, help="TSP size n (d = n(n-1)/2)")
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step")
-    ap.add_argument("--instances", type=int, default=1000, help="distinct instances in the dataset")
+    ap.add_argument("--instances", type=int, default=4096,
+                    help="distinct instances in the dataset (>= rotate * batch: every slot of every rotating batch is a "
+                         "different cone; BASELINE configs[1] names 1 000, which would repeat cones inside a batch of 1024)")
     ap.add_argument("--rotate", type=int, default=4, help="distinct batches the timed steps cycle through")
     ap.add_argument("--mode", default="inner", choices=["project", "exact", "inner"])
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances timed on the host for cpu_baseline (0=skip)")
@@ -51,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the pack stage of step i+1 (side stream) with the solve stage of step i "
                          "(measured: 182 vs 192 us/step -- the two kernels slow each other down; off by default)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even at --gpus 1 (world size 1) and run the per-step "
+                         "[sum loss, count] all-reduce and the sharded-store leg: the code path of an N-GPU run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / JSON-relay check without a GPU (gloo, no kernels; CPU tests)")
     return ap.parse_args(argv)
@@ -236,8 +241,13 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}")
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:  # before any other GPU call of this process
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -249,7 +259,9 @@ def main(argv=None):
     rng = np.random.default_rng(1234 + rank)
     batches = []
     for r in range(R):
-        ids = (np.arange(args.batch) + rank * args.batch + r * (args.instances // R + 7)) % args.instances
+        # batch r of this rank: `batch` consecutive instances starting at r * batch (+ a per-rank offset); with
+        # instances >= R * batch the R batches share no cone
+        ids = (np.arange(args.batch) + r * args.batch + rank * (args.batch // 2 + 13)) % args.instances
         pred_np = costs_np[ids] + rng.normal(0, 0.05, size=costs_np[ids].shape).astype(np.float32)
         batches.append((ids, pred_np, torch.tensor(ctrs_np[ids], device=dev), torch.tensor(pred_np, device=dev)))
     ids, pred_np, ctrs, pred = batches[0]
@@ -280,7 +292,7 @@ def main(argv=None):
             state["prep"] = prepare_dense(batches[(i + 1) % R][2], ready=mark)
         else:
             o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
-        if world > 1 and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
+        if use_dist and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
             red[0] = o["loss"].sum()
             red[1] = float(B)
             dist.all_reduce(red)
@@ -290,7 +302,7 @@ def main(argv=None):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -300,13 +312,13 @@ def main(argv=None):
         if i >= args.steps - R:
             status_all.append(o["status"])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert all(bool((s == 0).all()) for s in status_all), "solver reported failures"
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
@@ -363,23 +375,32 @@ def main(argv=None):
                                  "stream (cave_amd.qpsolver.prepare_dense); measured gain ~5 %: co-resident, the two "
                                  "kernels slow each other down (solve 130 -> 175 us, pack 60 -> 147 us)."},
         }
-        if not args.no_extras:
+        if use_dist:
+            res["process_group"] = {"backend": "nccl (RCCL)", "world_size": world,
+                                    "per_step_collective": "all_reduce([sum loss, count]), 8 bytes"}
+        # side measurements only in the single-process run: under N ranks they would keep rank 0 busy for tens of
+        # seconds while the others wait in a collective
+        if not args.no_extras and world == 1:
             res.update(extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs))
-            if not args.no_other_configs and world == 1:
+            if not args.no_other_configs:
                 res["other_configs"] = other_configs(dev)
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(ctrs_np[ids], -pred_np, args.cpu_sample, f"TSP-{args.tsp}")
             res["gpu_over_cpu_1core_nnls"] = res["value"] / res["cpu_baseline"]["value"]
+    # every rank reaches the sharded-store leg (collectives inside) right after the timed loop; rank 0 prints last
+    if use_dist:
+        shard = sharded_store_leg(args, ctrs_np, costs_np, dev, mode, outs, rank, world)
+        if rank == 0:
+            res["sharded_packed_store"] = shard
+    if rank == 0:
         print(json.dumps(res))
-    if world > 1 and not args.no_extras:
-        sharded_store_leg(args, ctrs_np, costs_np, dev, mode, outs, rank, world)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def sharded_store_leg(args, ctrs_np, costs_np, dev, mode, outs, rank, world):
-    """N > 1 side measurement (stderr, not the JSON line): the dataset's ragged cones are dealt to ranks
+    """Distributed side measurement (reported inside the JSON line): the dataset's ragged cones are dealt to ranks
     balanced by their non-zeros (ConeStore.from_ragged_shard) and every rank projects its whole shard."""
     import numpy as np
     import torch
@@ -404,10 +425,8 @@ def sharded_store_leg(args, ctrs_np, costs_np, dev, mode, outs, rank, world):
     tm = t.clone()
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    if rank == 0:
-        sys.stderr.write(json.dumps({"sharded_packed_store": {
-            "ranks": world, "instances": int(t[1]), "projections_per_s": float(t[1]) * 50 / float(tm[0]),
-            "max_shard_bytes": int(tm[2]), "balance": "sum of non-zeros (LPT)"}}) + "\n")
+    return {"ranks": world, "instances": int(t[1]), "projections_per_s": float(t[1]) * 50 / float(tm[0]),
+            "max_shard_bytes": int(tm[2]), "balance": "sum of non-zeros (LPT)"}
 
 
 def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):

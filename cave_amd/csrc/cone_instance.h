@@ -161,7 +161,12 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     w.y = y;
     w.bw = 0; w.band_wave = false; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
     if (mode == MODE_IPM) { warm_theta = nullptr; warm_state = nullptr; }  // the interior iterate is not a starting point
-    w.warm = (warm_theta && warm_state && *warm_state == 1) ? warm_theta : nullptr;
+    // ONE thread reads the state byte and the workgroup agrees on it through a reduction: another workgroup
+    // solving the same store slot (a repeated id in the batch) may be rewriting it right now, and a decision that
+    // differed between waves would send them into different barrier sequences below.
+    bool warm_on = false;
+    if (warm_theta && warm_state) warm_on = c.reduce_add_u32(c.tid() == 0 ? (uint32_t)(*warm_state == 1) : 0u) != 0u;
+    w.warm = warm_on ? warm_theta : nullptr;
     if constexpr (LARGE) {
       const int bw = band_halfwidth(c, v);
       const uint32_t ld = (uint32_t)bw + 1u;
@@ -353,7 +358,9 @@ CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, i
   if constexpr (LARGE) ar.init(ws, ws_bytes);
   else ar.init(smem + C::SCRATCH_BYTES, P.lds_bytes - C::SCRATCH_BYTES);
   ConeBuild cb;
+  CAVE_T0();
   int32_t st = scan_and_build<C, LARGE>(c, ar, cb, P.ctrs + b * (int64_t)m * d, m, d, P.nnz_cap);
+  CAVE_ACC(0);
   if (!P.fill) {
     if (c.tid() == 0) {
       P.n_rows[b] = (st == ST_OK) ? cb.p : 0;
@@ -401,6 +408,7 @@ CAVE_HD void run_pack_instance(C& c, unsigned char* smem, const PackParams& P, i
       }
     }
   }
+  CAVE_ACC(1);
   if (S.n_rows != nullptr && c.tid() == 0) {
     S.n_rows[slot] = st == ST_OK ? cb.p : -1;  // -1: this slot holds no cone (the packed operator reports TOO_LARGE)
     S.n_nnz[slot] = st == ST_OK ? (int32_t)cb.nnzM : 0;

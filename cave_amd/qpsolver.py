@@ -8,7 +8,8 @@ from ``_batch_project`` src/cave.py:242-244), but with **nnls semantics**
 ``cone{lam @ ctrs_b : lam >= 0}``, zero-padded rows ignored, empty cone returns
 the input, ``rnorm`` is the un-squared residual norm.
 
-Everything runs in one HIP kernel launch per call (cave_amd/csrc/cave_hip.hip);
+One call is one HIP kernel launch (cave_amd/csrc/kernels.h), or two for small cones on the dense wire
+format (the "split" form below: a 4-wave streaming pack kernel, then a 1-wave solve kernel);
 this module only marshals pointers, picks launch limits and turns per-instance
 status codes into the reference's error behaviour.
 """
@@ -51,10 +52,11 @@ _wide_ok: dict[tuple[int, int], bool] = {}
 
 
 def _auto_waves(B: int, m: int, d: int, check: bool) -> int:
-    """Waves per instance when the caller leaves it open.  Measured on TSP-20 (dense): 4 waves 191 us,
-    2 waves 215 us, 1 wave 236 us at B = 1024; one wave per instance wins beyond ~1300 instances (more
-    instances in flight).  Four waves hold reduced systems up to 32 rows and are only used once a
-    status-checked launch has shown the shape fits."""
+    """Waves per instance of the FUSED dense kernel when the caller leaves it open (cones with d <= 256 normally
+    take the split form instead, see launch_split).  Four waves shorten the streaming scan while the GPU has idle
+    SIMDs (TSP-20, B = 1024, rotating batches, r02: 219 us with 4 waves, 193 with 2, 196 with 1); one wave per
+    instance wins beyond ~1300 instances (more instances in flight).  Four waves hold reduced systems up to 32
+    rows and are only used once a status-checked launch has shown the shape fits."""
     if B > 1280:
         return 1  # reduced systems up to 64 rows, like the 2-wave shape
     ok = _wide_ok.get((m, d))
@@ -136,6 +138,7 @@ class _SlotStore:
         self.ref = C.byref(self.c)
         self.pack_status = torch.empty(B, dtype=torch.int32, device=dev)
         self.lds_bytes = int(_lib.load_library().cave_hip_packed_lds_bytes(d, SPLIT_ROWS, SPLIT_NNZ, 1))
+        self.gen = 0  # bumped every time prepare_dense hands this store out (PreparedCones.stale)
 
 
 def _slot_store(dev, B: int, d: int) -> _SlotStore:
@@ -161,11 +164,18 @@ _prep_pool: dict = {}
 class PreparedCones:
     """A dense (B, m_max, d) batch whose reduced cones sit in a transient slot store (or are being put there on
     the side stream).  Usable once in place of `tight_ctrs` in a loss call; keeps the dense tensor alive for the
-    fallback of a batch that does not fit the slots."""
+    fallback of a batch that does not fit the slots -- or whose slot store has been handed to a later prepare()
+    in the meantime (`gen` no longer matches the store's: more prepared batches held than the pool has stores)."""
 
-    def __init__(self, ctrs: torch.Tensor, store, event):
-        self.ctrs, self.store, self.event = ctrs, store, event
+    def __init__(self, ctrs: torch.Tensor, store, event, gen: int):
+        self.ctrs, self.store, self.event, self.gen = ctrs, store, event, gen
         self.shape = tuple(ctrs.shape)
+
+    def stale(self) -> bool:
+        return self.gen != self.store.gen
+
+
+PREP_POOL = 3  # slot stores cycled by prepare_dense per (device, B, d): a DataLoader prefetch depth of up to 3
 
 
 def stream_mark(device=None) -> "torch.cuda.Event":
@@ -189,27 +199,35 @@ def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = N
         return tight_ctrs
     dev = tight_ctrs.device
     ctrs = _as_device(tight_ctrs, dev)
+    # Work this call itself enqueues on the CURRENT stream -- a dtype / layout conversion of the cones, the fills
+    # that initialise a new slot store -- is not covered by the caller's earlier mark: the side stream must wait
+    # for it too, or the pack would read unconverted cones / have its output zeroed afterwards.
+    fresh_work = ctrs.data_ptr() != tight_ctrs.data_ptr()
     pool = _prep_pool.setdefault((dev, B, d), [])
-    if len(pool) < 3:
+    if len(pool) < PREP_POOL:
         ss = _SlotStore(dev, B, d)
+        fresh_work = True
     else:
-        ss = pool.pop(0)  # round robin over three stores: the one handed out three calls ago has been consumed
+        ss = pool.pop(0)  # round robin: the store handed out PREP_POOL calls ago (its holder is stale from now on)
     pool.append(ss)
+    ss.gen += 1
     side = _side_streams.get(dev)
     if side is None:
         side = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    # the dense tensor must be ready; the slot store handed out was last read by a solve launched three prepare()
+    # the dense tensor must be ready; a recycled slot store was last read by a solve launched PREP_POOL prepare()
     # calls ago on the current stream, which an event of "now" (or the caller's earlier mark) covers too
-    if ready is None:
-        ready = stream_mark(dev)
-    side.wait_event(ready)
+    if ready is None or fresh_work:
+        side.wait_event(stream_mark(dev))
+    if ready is not None:
+        side.wait_event(ready)
+    ctrs.record_stream(side)
     with torch.cuda.stream(side):
         rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, 0, 0, 4, ss.ref, 0, _lib.ptr(ss.pack_status),
                                     C_void(side.cuda_stream))
         _lib.check(rc, "cave_hip_pack_fill (slot mode, side stream)")
         ev = torch.cuda.Event()
         ev.record(side)
-    return PreparedCones(ctrs, ss, ev)
+    return PreparedCones(ctrs, ss, ev, ss.gen)
 
 
 def C_void(x):
@@ -227,6 +245,8 @@ def cone_op_prepared(prep: PreparedCones, pred_cost: torch.Tensor, mode: int, si
     lib = _lib.load()
     B, m, d = prep.shape
     dev = prep.ctrs.device
+    if prep.stale():  # its slot store now holds a later batch: solve from the dense tensor it kept
+        return cone_op_dense(prep.ctrs, pred_cost, mode, sign, inner_ratio, max_iter=max_iter, check=check, outputs=outputs)
     pred = _as_device(pred_cost, dev)
     if pred.shape != (B, d):
         raise ValueError(f"pred_cost must have shape ({B}, {d}), got {tuple(pred.shape)}")

@@ -1,0 +1,186 @@
+"""GPU tier, round-3 additions: the review items of round 2 (warm start with repeated ids, the prepared form's stream
+ordering and store generations, RCCL at world size 1) and the large-cone path work of this round (determinism,
+the `waves` argument of ABI v8, interior-point inner mode on large cones)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from golden_cases import MODE_INNER, MODE_PROJECT
+
+ALL = ("proj", "rnorm", "target", "loss", "grad")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_warm_start_with_repeated_ids():
+    """A batch may name one store slot several times while the multiplier cache is on (bench.py did: 1024 ids over
+    1000 instances).  The workgroups of the repeats read and rewrite that slot's state concurrently; the decision to
+    start warm is taken once per workgroup, so every wave shape must finish, and the projection (unique) must equal
+    the cold one on every copy.  LDS path at 1 / 2 / 4 waves, and the large-cone path."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+
+    rng = np.random.default_rng(5)
+    for kind in ("tsp20", "sp12"):
+        if kind == "tsp20":
+            ctrs, costs, _ = synth.tsp_batch(20, 24, seed=9)
+        else:
+            ctrs, costs, _ = synth.sp_batch(12, 12, 24, seed=9)
+        c = torch.tensor(ctrs, device="cuda")
+        cold, warm = ConeStore.from_dense(c), ConeStore.from_dense(c)
+        assert cold.large == (kind == "sp12")
+        warm.enable_warm_start()
+        ids = torch.tensor(rng.integers(0, 6, size=96), device="cuda")  # 96 slots of the batch over 6 instances
+        sc = float(np.abs(costs).max())
+        for waves in ((2, 4, 1) if kind == "tsp20" else (4, 2)):
+            cold.waves = warm.waves = waves
+            cold.large_waves = warm.large_waves = waves
+            warm.reset_warm_start()
+            pred = torch.tensor(costs[ids.cpu().numpy()], device="cuda")
+            for step in range(3):
+                a = cold.cone_op(ids, pred, MODE_INNER, -1.0, 0.2, outputs=ALL)
+                b = warm.cone_op(ids, pred, MODE_INNER, -1.0, 0.2, outputs=ALL)
+                assert bool((b["status"] == 0).all())
+                for k in ALL:
+                    tol = 4e-6 * (sc if k in ("proj", "rnorm") else 4.0)
+                    assert float((a[k] - b[k]).abs().max()) <= tol, (kind, waves, step, k)
+                pred = pred + torch.tensor(rng.normal(0, 0.01, pred.shape).astype(np.float32), device="cuda")
+
+
+def test_prepared_form_from_the_first_step_and_beyond_the_pool():
+    """qpsolver.prepare_dense(ready=stream_mark()) from the very first step (the fills that initialise a
+    new slot store are enqueued on the current stream AFTER the mark; the side stream has to wait for them too),
+    and more prepared batches held at once than the pool has slot stores (a stale one falls back to its dense
+    tensor instead of solving another batch's cones)."""
+    import torch
+
+    from cave_amd import qpsolver, synth
+    from cave_amd.qpsolver import PREP_POOL, PreparedCones, cone_op_dense, cone_op_prepared, prepare_dense, stream_mark
+
+    ctrs, costs, _ = synth.tsp_batch(20, 96, seed=21)
+    rng = np.random.default_rng(8)
+    batches = [(torch.tensor(ctrs[rng.permutation(96)[:40]], device="cuda"),
+                torch.tensor(costs[:40] + rng.normal(0, 0.1, (40, costs.shape[1])).astype(np.float32), device="cuda"))
+               for _ in range(PREP_POOL + 3)]
+    want = [cone_op_dense(c, p, MODE_INNER, -1.0, 0.2, outputs=ALL) for c, p in batches]
+    qpsolver._prep_pool.clear()  # every store of this run is created inside the loop below
+    # a long-running kernel on the current stream, then a mark, then the prepare: the pack may only wait for the mark
+    big = torch.randn(4096, 4096, device="cuda")
+    prep = None
+    for i, (c, p) in enumerate(batches):
+        _ = big @ big  # keeps the current stream busy when the pack is enqueued
+        mark = stream_mark()
+        nxt = prepare_dense(c, ready=mark)
+        assert isinstance(nxt, PreparedCones)
+        got = cone_op_prepared(nxt, p, MODE_INNER, -1.0, 0.2, outputs=ALL)
+        for k in ALL:
+            assert torch.equal(got[k], want[i][k]), (i, k)
+    # hold PREP_POOL + 2 prepared batches before consuming any
+    held = [prepare_dense(c) for c, _ in batches[:PREP_POOL + 2]]
+    assert sum(h.stale() for h in held) == 2 and held[0].stale() and not held[-1].stale()
+    for i, h in enumerate(held):
+        got = cone_op_prepared(h, batches[i][1], MODE_INNER, -1.0, 0.2, outputs=ALL)
+        for k in ALL:
+            assert torch.equal(got[k], want[i][k]), ("held", i, k)
+    # float64 cones: the conversion is this call's own work on the current stream
+    c64 = batches[0][0].double()
+    got = cone_op_prepared(prepare_dense(c64, ready=stream_mark()), batches[0][1], MODE_INNER, -1.0, 0.2, outputs=ALL)
+    for k in ALL:
+        assert torch.equal(got[k], want[0][k]), ("f64", k)
+
+
+_RCCL_SCRIPT = r"""
+import json, os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "tests")]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str({port}), RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+# the process group FIRST, before any other GPU call of this process (what an N-GPU rank does)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
+import numpy as np
+from cave_amd import synth
+from cave_amd.cave import EPO, innerConeAlignedCosine
+from cave_amd.dataset import ConeStore
+from cave_amd.dist import global_mean_loss, same_branch_seed, allreduce_grads_sum
+class M: modelSense = EPO.MINIMIZE
+ctrs, costs, _ = synth.tsp_batch(12, 48, seed=2)
+seed = same_branch_seed(4321)
+assert seed == 4321
+pred = torch.tensor(costs, device="cuda", requires_grad=True)
+c = torch.tensor(ctrs, device="cuda")
+mod = innerConeAlignedCosine(M(), solver="hip", seed=seed, reduction="none")
+per = mod(pred, c)
+g = global_mean_loss(per)            # the [sum loss, count] all-reduce over RCCL
+g.backward()
+grad_dist = pred.grad.clone()
+pred.grad = None
+mod2 = innerConeAlignedCosine(M(), solver="hip", seed=seed, reduction="mean")
+l2 = mod2(pred, c)
+l2.backward()
+red = torch.stack([per.detach().sum(), torch.tensor(float(per.numel()), device="cuda")])
+dist.all_reduce(red)
+lin = torch.nn.Linear(3, 5).cuda()
+lin(torch.ones(2, 3, device="cuda")).sum().backward()
+w0 = lin.weight.grad.clone()
+allreduce_grads_sum(lin.parameters())
+ragged = [torch.from_numpy(x[np.abs(x).sum(axis=1) > 0]) for x in ctrs]
+store = ConeStore.from_ragged_shard(ragged, 0, 1)
+o = store.cone_op(torch.arange(store.n, device="cuda"), pred.detach(), 2, -1.0, 0.2, outputs=("loss",))
+dist.barrier()
+out = dict(loss_dist=float(g), loss_plain=float(l2), grad_diff=float((grad_dist - pred.grad).abs().max()),
+           red=[float(red[0]), float(red[1])], wdiff=float((w0 - lin.weight.grad).abs().max()),
+           shard_n=store.n, shard_loss=float(o["loss"].mean()), backend=dist.get_backend())
+dist.destroy_process_group()
+print("RCCL_RESULT " + json.dumps(out))
+"""
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_process_group_at_world_size_one():
+    """The code path an N-GPU run takes, on the one GPU of this box: `nccl` (= RCCL) initialised with one rank before
+    any other GPU call, then dist.same_branch_seed, dist.global_mean_loss (the per-step [sum loss, count]
+    all-reduce), the gradient sum-reduce and ConeStore.from_ragged_shard -- and the N = 1 values equal the
+    non-distributed ones.  Runs in a child process (a fresh one: nothing has touched the GPU before the group)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(root=ROOT, port=_free_port())], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL_RESULT ")]
+    assert line, r.stdout[-2000:]
+    o = json.loads(line[-1][len("RCCL_RESULT "):])
+    assert o["backend"] == "nccl"
+    assert abs(o["loss_dist"] - o["loss_plain"]) <= 1e-6 and o["grad_diff"] <= 1e-7, o
+    assert o["red"][1] == 48.0 and abs(o["red"][0] / 48.0 - o["loss_plain"]) <= 1e-5, o
+    assert o["wdiff"] == 0.0 and o["shard_n"] == 48 and abs(o["shard_loss"] - o["loss_plain"]) <= 1e-5, o
+
+
+def test_bench_force_dist_single_gpu():
+    """`bench.py --gpus 1 --force-dist`: the bench's own distributed legs (process group, per-step all-reduce,
+    barrier-bracketed timing, sharded packed store) at world size 1."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "5",
+                        "--warmup", "2", "--cpu-sample", "0", "--instances", "1024", "--rotate", "1", "--batch", "256", "--no-extras"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert line, r.stdout[-2000:]
+    res = json.loads(line[-1])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["process_group"]["world_size"] == 1
+    assert res["sharded_packed_store"]["instances"] == 1024 and res["sharded_packed_store"]["projections_per_s"] > 0

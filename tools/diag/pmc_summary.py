@@ -14,15 +14,15 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof2"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 kerns = (sys.argv[3] if len(sys.argv) > 3 else "cone_dense_kernel").split(",")
 out = {"kernels": {}, "workload": sys.argv[4] if len(sys.argv) > 4 else "tsp20_b1024_inner",
        "split": any("cone_pack_kernel" in k for k in kerns)}
 tot_r = tot_w = 0.0
 for kern in kerns:
     o = {}
-    for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_ic", "pmc_inst", "pmc_ic2"):
         fs = sorted(glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
         if not fs:
             continue
@@ -47,6 +47,10 @@ for kern in kerns:
     if "SQ_WAVE_CYCLES" in o:
         o["wait_share"] = o.get("SQ_WAIT_ANY", 0.0) / o["SQ_WAVE_CYCLES"]
         o["issue_share"] = o.get("SQ_ACTIVE_INST_ANY", 0.0) / o["SQ_WAVE_CYCLES"]
+        if "SQ_WAIT_INST_ANY" in o:
+            o["issue_stall_share"] = o["SQ_WAIT_INST_ANY"] / o["SQ_WAVE_CYCLES"]
+    if o.get("SQC_ICACHE_REQ"):
+        o["icache_miss_rate"] = o.get("SQC_ICACHE_MISSES", 0.0) / o["SQC_ICACHE_REQ"]
     out["kernels"][kern] = o
 if tot_r:
     out["hbm_read_bytes_per_launch"], out["hbm_write_bytes_per_launch"] = tot_r, tot_w
