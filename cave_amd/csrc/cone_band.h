@@ -273,7 +273,7 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
     constexpr int TX = NT >= 64 ? 32 : 1, TY = NT / TX;
     const int tx = tid % TX, ty = tid / TX;
     bool blocked = false;
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
     if constexpr (HOT && C::WL == 64) blocked = p <= 127 && 2 * CH * ld >= 8 * (p + 2);
     if constexpr (HOT && C::WL == 64) if (blocked) {
       // Four pivots per step, as in solve_spd_band_wave below: wave 0 eliminates the four pivot rows against each
@@ -500,7 +500,7 @@ CAVE_HOSTDEV uint32_t band_wave_staging(int bw, int p) {
   return a > b ? a : b;
 }
 
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
 // ------------------------------------------------------------------ narrow bands on ONE wave
 // What the team form above costs on a 30x30 grid (bw = 30, p = 900; rocprof + the stamp build): every pivot is a
 // workgroup barrier plus ~200 instructions in EACH of the four waves for 465 window updates -- the kernel is
@@ -554,8 +554,8 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   const int wave = __builtin_amdgcn_readfirstlane(wave_v);
   const int bw = __builtin_amdgcn_readfirstlane(bw_v), p = __builtin_amdgcn_readfirstlane(p_v);
   auto bar = [&]() __attribute__((always_inline)) {  // orders the LDS traffic of the waves
-    if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("" ::: "memory");
+    if constexpr (NW > 1) CAVE_LDS_BARRIER();
+    else CAVE_WAVE_ORDER();
   };
   if (wave >= NWE) {
     bar();
@@ -858,7 +858,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     chi_next -= CHB;
     if (chi_next >= 0) fetch_b(chi_next);
   }
-  asm volatile("" ::: "memory");
+  CAVE_WAVE_ORDER();
   {
     double acc = 0.0;  // partial sum of the row this lane owns (row = lane mod 64)
     const int rowbase = lane * rs;
@@ -867,7 +867,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         park_b(chi_next);
         chi_next -= CHB;
         if (chi_next >= 0) fetch_b(chi_next);
-        asm volatile("" ::: "memory");
+        CAVE_WAVE_ORDER();
       }
     };
     // entry t of factor row r, zero past the band (scalar address: every lane reads the same word)
@@ -882,7 +882,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       const bool own = lane == (k & 63);
       acc = own ? 0.0 : fma(fcol, xk, acc);
       if (own) x[k] = xk;
-      asm volatile("" ::: "memory");
+      CAVE_WAVE_ORDER();
     }
     // then NB = 4 rows per step: the four unknowns from one batch of loads (the 4x4 triangle between them as
     // scalars), after which every lane folds all four into its row's partial sum -- same fma order as row by row
@@ -920,12 +920,12 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       const int mine = (k - lane) & 63;  // < NB: this lane owned one of the four rows; its sum starts over
       acc = mine < NB ? 0.0 : acc;
       if (lane < NB) x[k - lane] = lane == 0 ? x0 : (lane == 1 ? x1 : (lane == 2 ? x2 : x3));
-      asm volatile("" ::: "memory");
+      CAVE_WAVE_ORDER();
     }
   }
-  asm volatile("" ::: "memory");
+  CAVE_WAVE_ORDER();
   CAVE_ACC(12);
 }
-#endif  // __HIPCC__
+#endif  // CAVE_GPU_CODE
 
 }  // namespace cave

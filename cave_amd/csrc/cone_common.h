@@ -21,6 +21,29 @@
 #define CAVE_NOINLINE inline
 #endif
 
+// CAVE_GPU_CODE: the wave-level code (DPP / readlane / ballot: the one-wave lite solver, the one-/two-wave band
+// elimination, the blocked dense elimination) is compiled.  True under hipcc and in the SIMT emulation build of
+// tests/emul (CAVE_SIMT_EMUL: g++ with a shim <hip/hip_runtime.h> that runs every lane as a fiber), false in the
+// single-lane serial test build.
+#if defined(__HIPCC__) || defined(CAVE_SIMT_EMUL)
+#define CAVE_GPU_CODE 1
+#endif
+// Ordering points that exist only because a wave's lanes run in lockstep and its LDS operations execute in issue
+// order.  On the GPU they cost nothing (a compiler barrier) or an LDS-counter wait; the SIMT emulation turns them
+// into a rendezvous of the wave / workgroup -- so a hand-over the source does not mark computes garbage there.
+//   CAVE_WAVE_ORDER()   lanes of ONE wave exchange data through LDS across this point
+//   CAVE_LDS_WAIT()     the same, plus the wave's own LDS operations have completed (one-wave workgroups)
+//   CAVE_LDS_BARRIER()  workgroup barrier that waits for LDS traffic only (global loads stay in flight)
+#if defined(CAVE_SIMT_EMUL)
+#define CAVE_WAVE_ORDER() ::simt::wave_sync()
+#define CAVE_LDS_WAIT() ::simt::wave_sync()
+#define CAVE_LDS_BARRIER() ::simt::block_sync()
+#elif defined(__HIPCC__)
+#define CAVE_WAVE_ORDER() asm volatile("" ::: "memory")
+#define CAVE_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define CAVE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 // ---- optional phase timing (diagnostic builds only: -DCAVE_STAMPS; never in the shipped library).
 // Cycle deltas are summed in per-wave registers (WaveCtx::st) and stored once per instance.
 #if defined(CAVE_STAMPS) && defined(__HIPCC__)
@@ -41,7 +64,7 @@ namespace cave {
 // Code that knows where an array lives casts once and gets ds_* / global_* instructions.
 template <class T, int SPACE>  // SPACE: 0 generic, 1 global, 3 LDS
 struct SpacePtr { using type = T*; };
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
 template <class T> struct SpacePtr<T, 1> { using type = __attribute__((address_space(1))) T*; };
 template <class T> struct SpacePtr<T, 3> { using type = __attribute__((address_space(3))) T*; };
 #endif
@@ -137,6 +160,26 @@ struct SolveView {
   const uint32_t* longrow;  // ... and their indices
 };
 
+// Dense reduced systems of the large-cone path (cone_dense.h): everything in LDS
+struct DenseWork {
+  bool on;         // this instance takes the dense path
+  int nF, nI, ldS; // rows with free multipliers (eliminated first), rows with bounds, row stride of S
+  double* A;       // [fold_entries(p)]  H, then its factor (int64 fixed point while being accumulated)
+  double* dinv;    // [p]  reciprocal pivots of the eliminated rows
+  double* z;       // [p]  right-hand side, eliminated alongside
+  double* x;       // [p]  solution, in elimination order
+  double* scr;     // [dense_scratch_entries(p)]  operands of one block step
+  uint16_t* pos;   // [p]  position of reduced row i in the elimination order
+  uint16_t* ord;   // [p]  reduced row at position q
+  double* S;       // [nI * ldS]  Schur complement of the bound rows, both triangles
+  double* sg;      // [nI]  reduced model gradient at the working point
+  double* st;      // [nI]  working point (multipliers of the bound rows)
+  double* ss;      // [nI]  step of one inner round
+  double* sr;      // [nI]  right-hand side / S * step
+  uint8_t* sact;   // [nI]  held at zero
+  double hscale, hinv;  // fixed-point scale of the accumulation and its reciprocal
+};
+
 struct SolveWork {
   float* y;        // [d]
   double* res;     // [d]  residual y - M^T theta (unclipped while iterating, clipped on return)
@@ -163,6 +206,7 @@ struct SolveWork {
   double* bz;      // [p] right-hand side being eliminated
   double* bstg;    // [2*bch*(bw+1)] staging buffers for rows streamed from / to the workspace
   int bch;         // rows per staged chunk
+  DenseWork dn;    // dense form (p <= bw + 1, p <= 128: TSP-100)
 };
 
 struct SolveResult {

@@ -44,7 +44,7 @@
 #define CAVE_ACCF(slot) do {} while (0)
 #endif
 #include "cone_common.h"
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
 #include "wave_prims.h"
 #endif
 #include "cone_band.h"
@@ -482,7 +482,8 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
 struct LiteCone {
   const uint32_t* ell;    // [4 * d]            (16-byte aligned)
   const uint32_t* csr16;  // [4 * 64 * chn8 / 8 ... ] = 32 * chn8 words (16-byte aligned)
-  double* pfx;            // [64 * chn8 + 1]    prefix sums, slot c * 64 + lane; the last slot stays 0
+  double* pfx;            // [64 * chn8 + 1 + 65] per-lane running sums, slot c * 64 + lane; slot 64 * chn8 stays 0; then
+                          //                    lbase[65]: sum of the lanes before lane l (lbase[64] = 0 goes with the zero slot)
   const uint16_t* pend;   // [p + 1]            pend[i + 1]: slot of the last entry of row i (pend[0]: the zero slot)
   int chn8;               // CSR entries per lane: 8 or 16
   int cmax;               // largest column count
@@ -490,9 +491,10 @@ struct LiteCone {
 static constexpr int kLiteMaxRows = 32, kLiteMaxD = 256, kLiteMaxCol = 8, kLiteMaxChunk = 16;
 static constexpr uint32_t kLiteDummyRow = 32;
 
+CAVE_HOSTDEV uint32_t lite_chunk(uint32_t nnz) { return nnz <= 512u ? 8u : 16u; }
 CAVE_HOSTDEV uint32_t lite_lds_bytes(int d, uint32_t nnz) {
-  const uint32_t chn8 = nnz <= 512u ? 8u : 16u;
-  return 16u * (uint32_t)d + 128u * chn8 + 8u * (64u * chn8 + 1u) + 2u * 34u + 64u;
+  const uint32_t chn8 = lite_chunk(nnz);
+  return 16u * (uint32_t)d + 128u * chn8 + 8u * (64u * chn8 + 1u + 65u) + 2u * 34u + 64u;
 }
 
 // Build the lite structures (all threads of the context).  Returns false when the cone does not qualify or the
@@ -504,10 +506,10 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
   if (!v.pm1 || p < 1 || p > kLiteMaxRows || d > kLiteMaxD) return false;
   const uint32_t nnz = v.mptr[p];
   if (nnz == 0u || nnz > 64u * (uint32_t)kLiteMaxChunk) return false;
-  const uint32_t chn8 = nnz <= 512u ? 8u : 16u;
+  const uint32_t chn8 = lite_chunk(nnz);
   uint32_t* ell = ar.try_get<uint32_t, 16u>(4u * (uint32_t)d);
   uint32_t* csr16 = ell ? ar.try_get<uint32_t, 16u>(32u * chn8) : nullptr;
-  double* pfx = csr16 ? ar.try_get<double>(64u * chn8 + 1u) : nullptr;
+  double* pfx = csr16 ? ar.try_get<double>(64u * chn8 + 1u + 65u) : nullptr;
   uint16_t* pend = pfx ? ar.try_get<uint16_t>(34u) : nullptr;
   if (!pend) return false;
   // columns -> ELL rows of 8 (unused slots: the dummy row)
@@ -544,7 +546,7 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
     }
     pend[i] = (uint16_t)slot;
   }
-  if (c.tid() == 0) pfx[64u * chn8] = 0.0;
+  if (c.tid() == 0) { pfx[64u * chn8] = 0.0; pfx[64u * chn8 + 1u + 64u] = 0.0; }
   over = c.reduce_add_u32(over);
   L.cmax = (int)c.reduce_max(cm);
   c.sync();
@@ -553,7 +555,7 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
   return true;
 }
 
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
 // +-x with the sign taken from bit 15 of a 16-bit entry (no select: the sign bit is xor-ed in)
 __device__ __forceinline__ double lite_signed(double x, uint32_t entry) {
   return __hiloint2double(__double2hiint(x) ^ (int)((entry & 0x8000u) << 16), __double2loint(x));
@@ -590,11 +592,13 @@ __device__ __forceinline__ void lite_gather(C& c, const LiteCone& L, int d, cons
   c.sync();
 }
 
-// g = -M rc by prefix sums (rc[d] = 0 is the dummy coordinate)
+// g = -M rc by prefix sums (rc[d] = 0 is the dummy coordinate).  Each lane stores the running sums of its own run
+// as it forms them; the sum of the lanes before it (one wave scan of the lane totals) goes to lbase[lane] and is
+// added when a row's two end points are read: (run + base) as before, so the bits are those of the form that kept
+// every running sum in registers until the scan was done -- which cost 2 VGPRs per entry of the run.
 template <class C>
 __device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, const double* rc, double* g) {
   const int lane = c.lane_id();
-  double pre[kLiteMaxChunk];
   double run = 0.0;
 #pragma unroll
   for (int g8 = 0; g8 < kLiteMaxChunk / 8; ++g8) {
@@ -607,16 +611,18 @@ __device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, co
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         run += lite_signed(val[u], w[u >> 1] >> ((u & 1) * 16));
-        pre[g8 * 8 + u] = run;
+        L.pfx[(g8 * 8 + u) * 64 + lane] = run;
       }
     }
   }
-  const double base = wave_inclusive_scan_f64(run) - run;  // sum of the lanes before this one
-#pragma unroll
-  for (int cc = 0; cc < kLiteMaxChunk; ++cc)
-    if (cc < L.chn8) L.pfx[cc * 64 + lane] = base + pre[cc];
+  double* lbase = L.pfx + 64 * L.chn8 + 1;
+  lbase[lane] = wave_inclusive_scan_f64(run) - run;  // sum of the lanes before this one
   c.sync();
-  if (lane < p) g[lane] = L.pfx[L.pend[lane + 1]] - L.pfx[L.pend[lane]];
+  if (lane < p) {
+    const uint32_t s1 = L.pend[lane + 1], s0 = L.pend[lane];
+    const uint32_t zs = 64u * (uint32_t)L.chn8;  // the zero slot pairs with lbase[64] = 0
+    g[lane] = (lbase[s1 == zs ? 64u : (s1 & 63u)] + L.pfx[s1]) - (lbase[s0 == zs ? 64u : (s0 & 63u)] + L.pfx[s0]);
+  }
   c.sync();
 }
 // H += (w_k - w_k_old) m_k m_k^T for the coordinates whose smoothed weight changed (see solve_cone_impl), lite
@@ -674,7 +680,7 @@ __device__ __forceinline__ void lite_hessian(C& c, const LiteCone& L, const Solv
     });
   }
 }
-#endif  // __HIPCC__
+#endif  // CAVE_GPU_CODE
 
 // phi'(alpha) and phi''(alpha) of phi(alpha) = 1/2 || Pi(r - alpha q) ||^2
 template <class C>
@@ -734,20 +740,24 @@ CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
   return alpha;
 }
 
+}  // namespace cave
+#include "cone_dense.h"
+namespace cave {
+
 // does the context carry the lite index structures (SoloCtx)?
 template <class C, class = void> struct ctx_lite : std::false_type {};
 template <class C> struct ctx_lite<C, std::void_t<decltype(C::LITE)>> : std::bool_constant<C::LITE> {};
 
 template <class C, bool PM1>
 CAVE_HD void gradient_any(C& c, const SolveView& v, const double* rc, double* g) {
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
   if constexpr (ctx_lite<C>::value) { lite_gradient(c, c.lite, v.p, rc, g); return; }
 #endif
   gradient<C, PM1>(c, v, rc, g);
 }
 template <class C, bool PM1>
 CAVE_HD void gather_any(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
   if constexpr (ctx_lite<C>::value) { lite_gather(c, c.lite, v.d, base, th, sgn, out); return; }
 #endif
   gather_mt<C, PM1>(c, v, base, th, sgn, out);
@@ -809,7 +819,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     f = refresh_clipped(c, v, r, rc);
   }
   const int ldh = w.ldh;
-  for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+  bool dense_on = false;
+  if constexpr (BAND) dense_on = w.dn.on;
+  if (!dense_on) for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
   if constexpr (!BAND) for (int k = c.tid(); k < d; k += NT) w.wold[k] = 0.f;
   c.sync();
   double reg_rel = 1e-12;  // Levenberg shift relative to max diag(H); raised when a step stalls
@@ -893,17 +905,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       const bool in_lds = w.band_hot && p <= ldh;
       double mu = (it < 6) ? CAVE_BMU0 * ymax * sched01 : 0.0;
       mu = fmax(mu, CAVE_BMU_COEF * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
-      auto weight = [&](int k) -> double {
-        const uint8_t u = v.usign[k];
-        if (u == 0) return 1.0;
-        if (u == 3) return 0.0;
-        const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
-        if (mu > 0.0) {
-          const double z = t / mu;
-          return 0.5 * (1.0 + z / sqrt(1.0 + z * z));
-        }
-        return (t > 0.0) ? 1.0 : 0.0;
-      };
+      auto weight = [&](int k) -> double { return band_weight(v.usign[k], r[k], mu); };
+      if (dense_on) dense_hessian<C, PM1>(c, v, r, mu, w.dn);  // whole matrix in LDS, fixed point (cone_dense.h)
+      else {
       auto accumulate = [&](auto Hacc, auto add) {
         for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
         c.sync();
@@ -960,6 +964,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       } else {
         accumulate(w.H, [&](double* q, double x) { c.atomic_add_f64(q, x); });
       }
+      }
     } else {
     // generalised Hessian H = M W M^T, kept incrementally: H += (w_k - w_k_old) m_k m_k^T for the coordinates
     // whose weight changed.  Far from its kink a coordinate has the 0/1 activity D_kk = [Pi(r)_k != 0]; within
@@ -975,7 +980,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       const double mu = CAVE_MU_COEF * ymax * fmin(pgn / g0n, cap07);
       const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
       bool done = false;
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
       if constexpr (ctx_lite<C>::value) { lite_hessian(c, c.lite, v, w, r, mu, inv_mu); done = true; }
 #endif
       if (!done)
@@ -1016,6 +1021,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // ---- model minimisation over theta >= 0 (attempt 0: free every bound variable with
     //      a negative multiplier; attempt 1, only if that made no move: free the most negative one)
     bool moved = false;
+    if (dense_on) {
+      // dense form: ONE factorisation of the rows without bounds, the active-set loop on the Schur complement of
+      // the others (cone_dense.h)
+      if constexpr (BAND) moved = dense_model_step(c, v, w.dn, theta, w.g, tc, reg_rel);
+    } else
     for (int attempt = 0; attempt < 2 && !moved; ++attempt) {
       double gmin = 0.0;
       if (attempt == 1) {
@@ -1041,7 +1051,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         c.sync();
         CAVE_ACC(4);
         if constexpr (BAND) {
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
           if (w.band_wave) {
             solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg
 #ifdef CAVE_STAMPS
@@ -1147,7 +1157,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           rk[j] = r[k];
           uk[j] = v.usign[k];
           double q = 0.0;
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
           if constexpr (ctx_lite<C>::value) {
             q = lite_col_dot(c.lite, k, w.dv);
           } else

@@ -1,0 +1,466 @@
+// cone_dense.h — Newton systems of DENSE reduced matrices too large for registers (large-cone path: TSP-100 has
+// ~100 degree equalities + a handful of subtour cuts, and M W M^T over them is full).
+//
+// What the round-2 form cost on TSP-100 (profiles/r02_large_path_phase_shares.txt): the smoothed Hessian was
+// accumulated with fp64 atomics (LDS, 16-64 lanes per address on the diagonal), copied to the global workspace, read
+// back into an LDS window, factored, the factor copied out and streamed back for the substitution -- and every bound
+// that blocked a step in the active-set inner loop started the factorisation over: at equal Newton counts the
+// instances of one batch took between 1.7 and 7.2 ms.  Here:
+//   * the whole matrix lives in LDS as the FOLDED upper triangle (row r and row p-1-r share one line of p+1 entries:
+//     45 KB at p = 105 instead of 89 KB, so two workgroups fit a CU) and is factored in place; nothing of it ever
+//     goes to global memory;
+//   * it is accumulated in 64-bit FIXED POINT (integer adds are associative: the result does not depend on the
+//     order in which the lanes arrive, two launches give the same bits), every lane owning a contiguous block of
+//     columns so that the lanes of one instruction hit different diagonal entries;
+//   * rows are eliminated in the order [rows that can never be at a bound (paired +a/-a rows: free multipliers) |
+//     rows with theta >= 0].  Eliminating the first block leaves, in the trailing corner, the Schur complement
+//     S = H_II - H_IF H_FF^-1 H_FI of the bound rows and, in z, the reduced right-hand side: the LDL^T is PAUSED
+//     there.  The active-set inner loop of the Newton step (ratio test, fix the blocking row, solve again) then
+//     runs on S alone -- nI x nI, a handful of rows, solved in registers -- and only its final answer is
+//     substituted back through the factor of the first block.  One O(p^3) factorisation per Newton iteration however
+//     many bounds block; the iterates of the bound rows are those of the full-space loop (the free rows are at
+//     their optimum for every trial point either way).
+// Semantics otherwise those of solve_spd_band: rows of H + reg_rel * max diag * I, a non-positive pivot drops its
+// row (x_k = 0).
+#pragma once
+#include "cone_common.h"
+
+namespace cave {
+
+constexpr int kDenseMaxP = 128;     // the pivot block is held two columns per lane
+constexpr int kDenseMaxBound = 32;  // bound rows: their Schur system is solved in registers (Ctx::solve_spd)
+constexpr int kDenseNB = 4;         // pivots per elimination step
+
+// Which reduced systems take this path: up to 128 rows whose band is full (p <= bw + 1) or too wide for the one-wave
+// band elimination of cone_band.h (half bandwidth > 34); narrow bands keep the band solvers.
+CAVE_HOSTDEV bool dense_shape(int p, int bw) { return p >= 1 && p <= kDenseMaxP && (p <= bw + 1 || bw >= 35); }
+
+CAVE_HOSTDEV uint32_t fold_entries(int p) { return (uint32_t)((p + 1) / 2) * (uint32_t)(p + 1); }
+// first entry (the diagonal) of row r of the folded upper triangle; entry (r, j >= r) sits at fold_base + (j - r)
+CAVE_HD int fold_base(int p, int r) {
+  const int h = (p + 1) / 2;
+  return r < h ? r * (p + 1) : (p - 1 - r) * (p + 1) + (r + 1);
+}
+CAVE_HOSTDEV uint32_t dense_scratch_entries(int p) { return 2u * (uint32_t)kDenseNB * (uint32_t)(p + 4); }
+// doubles of LDS the dense path needs for a reduced system of p rows, nI of them with bounds (+ 4 p bytes of indices)
+CAVE_HOSTDEV uint64_t dense_lds_bytes(int p, int nI) {
+  const uint64_t ldS = (uint64_t)(nI | 1);
+  return 8ull * (fold_entries(p) + 3ull * (uint64_t)p + dense_scratch_entries(p) + (uint64_t)nI * ldS + 4ull * (uint64_t)nI) +
+         4ull * (uint64_t)p + (uint64_t)nI + 128u;
+}
+
+// smoothed weight of coordinate k (see solve_cone_impl): derivative of the CHKS smoothing of the one-sided clip
+CAVE_HD double band_weight(uint8_t u, double rk, double mu) {
+  if (u == 0) return 1.0;
+  if (u == 3) return 0.0;
+  const double t = (u == 2) ? rk : -rk;  // > 0 on the side that carries residual
+  if (mu > 0.0) {
+    const double zz = t / mu;
+    return 0.5 * (1.0 + zz / sqrt(1.0 + zz * zz));
+  }
+  return (t > 0.0) ? 1.0 : 0.0;
+}
+
+// fixed-point scale for sums of products w * m_ak * m_bk, w in [0, 1]: |sum| <= vmax * rmax (largest entry times
+// largest row 1-norm) must stay below 2^61
+CAVE_HD double fixed_scale(double vmax, double rmax) {
+  const double bound = fmax(vmax * rmax, 1e-300);
+  int e = 0;
+  frexp(bound, &e);  // bound < 2^e
+  int sh = 61 - e;
+  if (sh > 1000) sh = 1000;
+  if (sh < -1000) sh = -1000;
+  return ldexp(1.0, sh);
+}
+
+// elimination order: rows with free multipliers first, rows with bounds last (both in their stored order)
+template <class C>
+CAVE_HD void dense_order(C& c, const SolveView& v, DenseWork& dw, uint32_t* tmp) {
+  const int p = v.p;
+  const uint32_t nF = c.compact_mask_u8(v.vkind, p, 0xff, 1, tmp);
+  c.sync();
+  for (int q = c.tid(); q < (int)nF; q += C::NT) { dw.ord[q] = (uint16_t)tmp[q]; dw.pos[tmp[q]] = (uint16_t)q; }
+  c.sync();
+  const uint32_t nI = c.compact_mask_u8(v.vkind, p, 0xff, 0, tmp);
+  c.sync();
+  for (int q = c.tid(); q < (int)nI; q += C::NT) { dw.ord[nF + q] = (uint16_t)tmp[q]; dw.pos[tmp[q]] = (uint16_t)(nF + q); }
+  c.sync();
+  dw.nF = (int)nF;
+  dw.nI = (int)nI;
+  dw.ldS = (int)(nI | 1u);
+}
+
+// A = M W M^T (folded upper triangle, elimination order), accumulated in fixed point.
+// (The pieces below are REAL calls, like the band solvers: inlined into the Newton iteration they inherit -- and add
+//  to -- a register file that already spills; as functions each gets its own allocation.)
+template <class C, bool PM1>
+CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, const double* r, double mu, const DenseWork& dw) {
+  constexpr int NT = C::NT;
+  const int p = v.p, d = v.d;
+  const int ne = (int)fold_entries(p);
+  auto Aq = space_cast<3>(reinterpret_cast<long long*>(dw.A));
+  auto Ad = space_cast<3>(dw.A);
+  auto pos = space_cast<3>(dw.pos);
+  for (int idx = c.tid(); idx < ne; idx += NT) Aq[idx] = 0;
+  c.sync();
+  const double sc = dw.hscale;
+  auto add = [&](int a, int b, double x) {  // a, b: positions
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    c.atomic_add_i64_lds(Aq + (fold_base(p, lo) + (hi - lo)), (long long)llrint(x * sc));
+  };
+  // Every thread owns a contiguous block of columns (the threads of one instruction then work on columns far
+  // apart: different diagonal entries, no same-address serialisation), G columns at a time with the column extents
+  // and the first E entries of each requested together: the cone is read from global memory (the packed store or
+  // the workspace), one dependent load per entry would cost a full memory latency each.
+  constexpr int G = 4, E = 4;
+  const int per = (d + NT - 1) / NT;
+  const int k0 = c.tid() * per;
+  const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
+  for (int u0 = 0; u0 < per; u0 += G) {
+    uint32_t lo[G], cnt[G], a[G][E];
+    double wk[G], x[G][E];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int k = k0 + u0 + u;
+      const bool in = (u0 + u) < per && k < d;
+      const int kc = in ? k : d - 1;
+      lo[u] = v.cptr[kc];
+      cnt[u] = in ? v.cptr[kc + 1] - lo[u] : 0u;
+      wk[u] = in ? band_weight(v.usign[kc], r[kc], mu) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t ee = lo[u] + (uint32_t)e < last ? lo[u] + (uint32_t)e : last;  // clamped: loads are unconditional
+        csc_entry<PM1>(v, ee, a[u][e], x[u][e]);
+      }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (!(wk[u] > 1e-14) || cnt[u] == 0u) continue;
+      int ap[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) ap[e] = (uint32_t)e < cnt[u] ? (int)pos[a[u][e]] : 0;
+#pragma unroll
+      for (int e1 = 0; e1 < E; ++e1) {
+        if ((uint32_t)e1 >= cnt[u]) break;
+        const double va = wk[u] * x[u][e1];
+#pragma unroll
+        for (int e2 = 0; e2 <= e1; ++e2) add(ap[e1], ap[e2], va * x[u][e2]);
+      }
+      for (uint32_t e1 = (uint32_t)E; e1 < cnt[u]; ++e1) {  // columns with more than E entries (edges inside several cuts)
+        uint32_t a1, a2;
+        double v1, v2;
+        csc_entry<PM1>(v, lo[u] + e1, a1, v1);
+        const double va = wk[u] * v1;
+        const int p1 = (int)pos[a1];
+        for (uint32_t e2 = 0; e2 <= e1; ++e2) {
+          csc_entry<PM1>(v, lo[u] + e2, a2, v2);
+          add(p1, (int)pos[a2], va * v2);
+        }
+      }
+    }
+  }
+  c.sync();
+  const double hi = dw.hinv;
+  for (int idx = c.tid(); idx < ne; idx += NT) {
+    const long long q = Aq[idx];
+    Ad[idx] = (double)q * hi;
+  }
+  c.sync();
+}
+
+// Partial LDL^T: pivots 0 .. nF-1 of A + reg I (reg = reg_rel * largest diagonal entry), the right-hand side z
+// eliminated alongside.  Afterwards rows < nF hold the rows of U (dinv: reciprocal pivots), rows >= nF the Schur
+// complement, z[nF ..] the reduced right-hand side.  Four pivots per step: wave 0 eliminates the four pivot rows
+// against each other in registers (lane t: columns k0 + t and k0 + t + 64) and publishes them and the multipliers;
+// after one barrier every lane takes the same TWO COLUMNS of every trailing row, so the eight pivot-row operands are
+// read once per step and a trailing row costs four broadcast reads, one read and one write of the target pair.
+template <class C>
+CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel) {
+  constexpr int NT = C::NT, NB = kDenseNB;
+  const int nF = dw.nF;
+  auto A = space_cast<3>(dw.A);
+  auto z = space_cast<3>(dw.z);
+  auto dinv = space_cast<3>(dw.dinv);
+  const int tid = c.tid();
+  double md = 0.0;
+  for (int i = tid; i < p; i += NT) md = fmax(md, A[fold_base(p, i)]);
+  md = c.reduce_max(md);
+  const double reg = reg_rel * md;
+  for (int i = tid; i < p; i += NT) A[fold_base(p, i)] += reg;
+  c.sync();
+#if defined(CAVE_GPU_CODE)
+  if constexpr (C::WL == 64) {
+    const int lane = c.lane_id(), wave = c.wave_id();
+    constexpr int NWV = NT / 64;
+    const int pc = p + 4;
+    auto scP = space_cast<3>(dw.scr), scQ = space_cast<3>(dw.scr) + NB * pc;
+    for (int k0 = 0; k0 < nF; k0 += NB) {
+      if (wave == 0) {
+        double u[NB][2], zv[NB], inv[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const int row = k0 + a;
+          const int rb = fold_base(p, row < p ? row : p - 1);
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int col = k0 + lane + 64 * g;
+            const bool in = row < p && col >= row && col < p;
+            const double val = A[in ? rb + (col - row) : 0];
+            u[a][g] = in ? val : 0.0;
+          }
+          const double zr = z[row < p ? row : p - 1];
+          zv[a] = row < p ? zr : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const double dk = readlane_f64(u[a][0], a);
+          const bool ok = (k0 + a < nF) && dk > 1e-300;
+          const double iv = ok ? 1.0 / dk : 0.0;
+          inv[a] = iv;
+#pragma unroll
+          for (int b = a + 1; b < NB; ++b) {
+            const double m = readlane_f64(u[a][0], b) * iv;
+            u[b][0] = fma(-m, u[a][0], u[b][0]);
+            u[b][1] = fma(-m, u[a][1], u[b][1]);
+            zv[b] = fma(-m, zv[a], zv[b]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int t = lane + 64 * g;  // column k0 + t; t = p - k0, p - k0 + 1: zero columns
+          if (t >= NB && t <= p - k0 + 1) {
+            const bool real = t < p - k0;
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+              scP[a * pc + t] = real ? u[a][g] : 0.0;
+              scQ[a * pc + t] = real ? u[a][g] * inv[a] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int a = 0; a < NB; ++a) {  // the block's rows as the earlier pivots of the block have left them
+            const int row = k0 + a, col = k0 + t;
+            if (row < p && col >= row && col < p) A[fold_base(p, row) + (col - row)] = u[a][g];
+          }
+        }
+        if (lane < NB && k0 + lane < p) {
+          z[k0 + lane] = lane == 0 ? zv[0] : (lane == 1 ? zv[1] : (lane == 2 ? zv[2] : zv[3]));
+          dinv[k0 + lane] = lane == 0 ? inv[0] : (lane == 1 ? inv[1] : (lane == 2 ? inv[2] : inv[3]));
+        }
+      }
+      c.sync_lds();
+      {
+        const int cb = k0 + NB;       // first trailing row / column
+        const int c0 = cb + 2 * lane; // this lane's columns c0, c0 + 1 (past p - 1: the zero columns)
+        const int t0 = c0 - k0 < pc - 1 ? c0 - k0 : pc - 2;
+        double p0[NB], p1[NB], zq[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          p0[a] = scP[a * pc + t0];
+          p1[a] = scP[a * pc + t0 + 1];
+          zq[a] = z[k0 + a < p ? k0 + a : p - 1];
+        }
+        for (int r = cb + wave; r < p; r += NWV) {
+          double q[NB];
+#pragma unroll
+          for (int a = 0; a < NB; ++a) q[a] = scQ[a * pc + (r - k0)];
+          const int o = fold_base(p, r) + (c0 - r);
+          const bool in0 = c0 >= r && c0 < p, in1 = c0 + 1 >= r && c0 + 1 < p;
+          double r0 = A[in0 ? o : 0], r1 = A[in1 ? o + 1 : 0];
+#pragma unroll
+          for (int a = 0; a < NB; ++a) {
+            r0 = fma(-q[a], p0[a], r0);
+            r1 = fma(-q[a], p1[a], r1);
+          }
+          if (in0) A[o] = r0;
+          if (in1) A[o + 1] = r1;
+          if (lane == 63) {  // an idle lane of the triangle takes the right-hand side of this row
+            double zz = z[r];
+#pragma unroll
+            for (int a = 0; a < NB; ++a) zz = fma(-q[a], zq[a], zz);
+            z[r] = zz;
+          }
+        }
+      }
+      c.sync_lds();
+    }
+    return;
+  }
+#endif
+  // plain right-looking form (serial test build)
+  for (int k = 0; k < nF; ++k) {
+    const int kb = fold_base(p, k);
+    const double dk = A[kb];
+    const double inv = dk > 1e-300 ? 1.0 / dk : 0.0;
+    if (tid == 0) dinv[k] = inv;
+    const double zk = z[k];
+    c.sync();
+    for (int r = k + 1 + tid; r < p; r += NT) {
+      const double m = A[kb + (r - k)] * inv;
+      const int rb = fold_base(p, r);
+      for (int j = r; j < p; ++j) A[rb + (j - r)] -= m * A[kb + (j - k)];
+      z[r] -= m * zk;
+    }
+    c.sync();
+  }
+}
+
+// x[q], q < nF, from the factor of the first block, the eliminated right-hand side and the given x[nF ..]
+template <class C>
+CAVE_NOINLINE void dense_backsub(C& c, const DenseWork& dw, int p) {
+  const int nF = dw.nF;
+  auto A = space_cast<3>(dw.A);
+  auto z = space_cast<3>(dw.z);
+  auto x = space_cast<3>(dw.x);
+  auto dinv = space_cast<3>(dw.dinv);
+#if defined(CAVE_GPU_CODE)
+  if constexpr (C::WL == 64) {
+    // column oriented, on wave 0: lane l owns the partial sums of rows l and l + 64; every finished x_k is folded
+    // into the rows above it with one fma per lane and row, so the loop-carried chain is a v_readlane pair and two
+    // fp64 operations.  (Needs p <= 128.)
+    if (c.wave_id() == 0) {
+      const int lane = c.lane_id();
+      const int r0 = lane, r1 = lane + 64;
+      const int b0 = fold_base(p, r0 < p ? r0 : 0), b1 = fold_base(p, r1 < p ? r1 : 0);
+      double acc0 = 0.0, acc1 = 0.0;
+      for (int j = nF; j < p; ++j) {  // the bound rows' part of the solution is given
+        const double xj = x[j];
+        const double u0 = A[r0 < nF ? b0 + (j - r0) : 0], u1 = A[r1 < nF ? b1 + (j - r1) : 0];
+        acc0 = fma(r0 < nF ? u0 : 0.0, xj, acc0);
+        acc1 = fma(r1 < nF ? u1 : 0.0, xj, acc1);
+      }
+      for (int k = nF - 1; k >= 0; --k) {
+        const double dk = dinv[k], zk = z[k];
+        const double u0 = A[r0 < k ? b0 + (k - r0) : 0], u1 = A[r1 < k ? b1 + (k - r1) : 0];
+        const double ak = (k & 64) ? readlane_f64(acc1, k & 63) : readlane_f64(acc0, k & 63);
+        const double xk = dk * (zk - ak);
+        acc0 = fma(r0 < k ? u0 : 0.0, xk, acc0);
+        acc1 = fma(r1 < k ? u1 : 0.0, xk, acc1);
+        if (lane == 0) x[k] = xk;
+      }
+    }
+    c.sync_lds();
+    return;
+  }
+#endif
+  if (c.tid() == 0)
+    for (int k = nF - 1; k >= 0; --k) {
+      const int kb = fold_base(p, k);
+      double s = z[k];
+      for (int j = k + 1; j < p; ++j) s -= A[kb + (j - k)] * x[j];
+      x[k] = dinv[k] * s;
+    }
+  c.sync();
+}
+
+// One model minimisation (the body of a Newton iteration between the Hessian and the line search) on the dense
+// path.  theta: current multipliers, g: gradient (both in reduced-row order).  On return tc holds the minimiser of
+// the model over theta >= 0 found by the active-set loop (as in solve_cone_impl: attempt 0 frees every bound
+// variable with a negative gradient, attempt 1 -- only if that made no move -- the most negative one);
+// returns whether tc differs from theta.  dw.A must hold the Hessian (dense_hessian).
+template <class C>
+CAVE_NOINLINE bool dense_model_step(C& c, const SolveView& v, const DenseWork& dw, const double* theta, const double* g,
+                              double* tc, double reg_rel) {
+  constexpr int NT = C::NT;
+  const int p = v.p, nF = dw.nF, nI = dw.nI, ldS = dw.ldS;
+  auto A = space_cast<3>(dw.A);
+  auto z = space_cast<3>(dw.z);
+  auto x = space_cast<3>(dw.x);
+  auto ord = space_cast<3>(dw.ord);
+  auto S = space_cast<3>(dw.S);
+  auto sg = space_cast<3>(dw.sg);
+  auto st = space_cast<3>(dw.st);
+  auto ss = space_cast<3>(dw.ss);
+  auto sr = space_cast<3>(dw.sr);
+  auto sact = space_cast<3>(dw.sact);
+  for (int q = c.tid(); q < p; q += NT) z[q] = -g[ord[q]];
+  c.sync();
+  dense_factor(c, dw, p, reg_rel);
+  // Schur complement of the bound rows as a full square (the register solver reads rows)
+  for (int idx = c.tid(); idx < nI * nI; idx += NT) {
+    const int i = idx / nI, j = idx - i * nI;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    S[i * ldS + j] = A[fold_base(p, nF + lo) + (hi - lo)];
+  }
+  c.sync();
+  bool moved = false;
+  for (int attempt = 0; attempt < 2 && !moved; ++attempt) {
+    double gmin = 0.0;
+    if (attempt == 1) {
+      double gl = 0.0;
+      for (int i = c.tid(); i < nI; i += NT) {
+        const int row = ord[nF + i];
+        if (theta[row] <= 0.0) gl = fmin(gl, g[row]);
+      }
+      gmin = -c.reduce_max(-gl);
+      if (!(gmin < 0.0)) break;
+    }
+    for (int i = c.tid(); i < nI; i += NT) {
+      const int row = ord[nF + i];
+      const bool at_bound = theta[row] <= 0.0;
+      const bool release = attempt == 0 ? (g[row] < 0.0) : (g[row] <= gmin);
+      sact[i] = (uint8_t)((at_bound && !release) ? 1 : 0);
+      st[i] = theta[row];
+      sg[i] = -z[nF + i];  // reduced model gradient at theta (the free rows at their optimum)
+    }
+    c.sync();
+    for (int inner = 0; inner <= nI && nI > 0; ++inner) {
+      for (int i = c.tid(); i < nI; i += NT) sr[i] = sact[i] ? -st[i] : -sg[i];
+      c.sync();
+#if defined(CAVE_GPU_CODE)
+      // (the register Gauss-Jordan at the sizes this path admits -- nI <= kDenseMaxBound = 32 --, not the context's
+      //  full dispatch up to 64 rows: a third of the code, half the registers)
+      if constexpr (C::WL == 64) { if (c.wave_id() == 0) gj_solve_small<kDenseMaxBound>(c.lane_id(), dw.S, ldS, dw.sr, dw.sact, nI, reg_rel, dw.ss); }
+      else
+#endif
+      c.solve_spd(dw.S, ldS, dw.sr, dw.sact, nI, reg_rel, dw.ss);
+      c.sync();
+      double amin = 2.0;
+      for (int i = c.tid(); i < nI; i += NT)
+        if (!sact[i]) {
+          const double t = st[i] + ss[i];
+          if (t < 0.0) amin = fmin(amin, st[i] / (st[i] - t));
+        }
+      amin = -c.reduce_max(-amin);
+      const bool blocked = amin < 1.0;
+      const double a = blocked ? fmax(amin, 0.0) : 1.0;
+      if (blocked) {
+        for (int i = c.tid(); i < nI; i += NT) {
+          double s = 0.0;
+          for (int j = 0; j < nI; ++j) s += S[i * ldS + j] * ss[j];
+          sr[i] = s;
+        }
+        c.sync();
+      }
+      for (int i = c.tid(); i < nI; i += NT) {
+        const double t = st[i] + ss[i];
+        double tn = st[i] + a * ss[i];
+        if (!sact[i] && blocked && t < 0.0 && st[i] <= a * (st[i] - t) * (1.0 + 1e-12)) {
+          tn = 0.0;
+          sact[i] = 1;
+        }
+        if (sact[i]) tn = 0.0;
+        st[i] = tn;
+        if (blocked) sg[i] += a * sr[i];
+      }
+      c.sync();
+      if (!blocked) break;
+    }
+    for (int i = c.tid(); i < nI; i += NT) x[nF + i] = st[i] - theta[ord[nF + i]];
+    c.sync();
+    dense_backsub(c, dw, p);
+    double mv = 0.0;
+    for (int q = c.tid(); q < p; q += NT) {
+      const int row = ord[q];
+      const double t = q < nF ? theta[row] + x[q] : st[q - nF];
+      tc[row] = t;
+      mv = fmax(mv, fabs(t - theta[row]));
+    }
+    moved = c.reduce_max(mv) > 0.0;
+    c.sync();
+  }
+  return moved;
+}
+
+}  // namespace cave

@@ -122,6 +122,13 @@ CAVE_HD SolveView view_of(const ConeBuild& cb) {
 }
 
 // hot-first allocation of the large-cone path: LDS while it lasts, then the global workspace
+#ifdef CAVE_EMUL_COUNTERS
+inline long* emul_counters() {  // test builds only: [0] dense path, [1] one-wave band path, [2] lite path, [3] H-free band
+  static long cnt[8] = {0};
+  return cnt;
+}
+#endif
+
 template <class T>
 CAVE_HD T* hot_get(Arena* hot, Arena& ar, uint32_t n) {
   if (hot) {
@@ -173,17 +180,62 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       if ((uint64_t)pp * ld > (1ull << 27) || ld > 4096u) return ST_TOO_LARGE;  // 1 GiB of band per instance
       w.bw = bw;
       w.ldh = (int)ld;
+      // Dense (or widely banded) reduced systems of up to 128 rows -- TSP-100 -- keep the whole matrix in LDS,
+      // folded, and factor it once per Newton iteration (cone_dense.h).
+      w.dn.on = false;
+      if (hot && p >= 1 && dense_shape(p, bw)) {
+        uint32_t cnt = 0;
+        for (int i = c.tid(); i < p; i += C::NT) cnt += v.vkind[i] ? 0u : 1u;
+        const int nI = (int)c.reduce_add_u32(cnt);
+        if (nI <= kDenseMaxBound && nI <= C::PMAX && (uint64_t)(hot->top - hot->off) >= dense_lds_bytes(p, nI) + 64u) {
+          DenseWork& dn = w.dn;
+          const uint32_t ldS = (uint32_t)(nI | 1), nb = (uint32_t)(nI > 0 ? nI : 1);
+          dn.A = hot->try_get<double, 16u>(fold_entries(p));
+          dn.dinv = hot->try_get<double>(pp);
+          dn.z = hot->try_get<double>(pp);
+          dn.x = hot->try_get<double>(pp);
+          dn.scr = hot->try_get<double, 16u>(dense_scratch_entries(p));
+          dn.S = hot->try_get<double>(nb * ldS);
+          dn.sg = hot->try_get<double>(nb);
+          dn.st = hot->try_get<double>(nb);
+          dn.ss = hot->try_get<double>(nb);
+          dn.sr = hot->try_get<double>(nb);
+          dn.pos = hot->try_get<uint16_t>(pp);
+          dn.ord = hot->try_get<uint16_t>(pp);
+          dn.sact = hot->try_get<uint8_t>(nb);
+          uint32_t* tmp = ar.get<uint32_t>(pp);
+          if (ar.ovf) return ST_TOO_LARGE;
+          if (dn.A && dn.dinv && dn.z && dn.x && dn.scr && dn.S && dn.sg && dn.st && dn.ss && dn.sr && dn.pos && dn.ord && dn.sact) {
+            dn.on = true;
+            dense_order(c, v, dn, tmp);
+            // fixed-point scale of the Hessian accumulation: |H_ab| <= (largest entry)^2 * (longest row)
+            double vm = v.pm1 ? 1.0 : 0.0, ml = 0.0;
+            if (!v.pm1) for (uint32_t e = c.tid(); e < v.mptr[p]; e += C::NT) vm = fmax(vm, fabs((double)v.mval[e]));
+            for (int i = c.tid(); i < p; i += C::NT) ml = fmax(ml, (double)(v.mptr[i + 1] - v.mptr[i]));
+            vm = c.reduce_max(vm);
+            ml = c.reduce_max(ml);
+            dn.hscale = fixed_scale(vm, vm * ml);
+            dn.hinv = 1.0 / dn.hscale;
+#ifdef CAVE_EMUL_COUNTERS
+            if (c.tid() == 0) ++emul_counters()[0];  // test builds: how many instances took the dense path
+#endif
+          }
+        }
+      }
       // narrow bands: the whole elimination runs on one wave (cone_band.h, solve_spd_band_wave)
       bool wave_mode = false;
-#if defined(__HIPCC__) && !defined(CAVE_NO_BAND_WAVE)  // (diagnostic builds can pin the team form of the band solver)
+#if defined(CAVE_GPU_CODE) && !defined(CAVE_NO_BAND_WAVE)  // (diagnostic builds can pin the team form of the band solver)
       if constexpr (C::WL == 64) {
         const uint64_t need = 8ull * (band_wave_window(bw) + 2ull * pp + band_wave_staging(bw, p)) + pp + 64u;
         wave_mode = hot != nullptr && band_wave_fits(bw, p) && (uint64_t)(hot->top - hot->off) >= need;
       }
 #endif
       // small, touched every elimination step / every inner round: LDS first
+      if (w.dn.on) wave_mode = false;
+      if (!w.dn.on) {
       w.bwin = hot_get<double>(hot, ar, wave_mode ? band_wave_window(bw) : ld * ld);
       w.bz = hot_get<double>(hot, ar, pp);
+      }
       w.step = hot_get<double>(hot, ar, pp);
       w.act = hot_get<uint8_t>(hot, ar, pp);
       // staging chunks: as many rows as the prefetch registers hold, fewer if that keeps them in LDS
@@ -193,11 +245,13 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
         const uint32_t room = (hot->top - hot->off) / (2u * 8u * ld);
         if (room >= 4u && room < (uint32_t)w.bch) w.bch = (int)room;
       }
-#if defined(__HIPCC__)
+      if (!w.dn.on) {
+#if defined(CAVE_GPU_CODE)
       if (wave_mode) w.bstg = hot_get<double>(hot, ar, band_wave_staging(bw, p));
       else
 #endif
       w.bstg = hot_get<double>(hot, ar, 2u * (uint32_t)w.bch * ld);
+      }
       w.g2 = hot_get<double>(hot, ar, pp);
       w.ttry = hot_get<double>(hot, ar, pp);
       w.told = hot_get<double>(hot, ar, pp);
@@ -208,14 +262,17 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       res = hot_get<double>(hot, ar, d);
       tvec = hot_get<double>(hot, ar, d);
       w.wold = nullptr;
+      if (!w.dn.on) {
       w.H = ar.get<double>(pp * ld);
       w.bfac = ar.get<double>(pp * ld);
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
       w.band_hot = hot && hot->owns(w.bwin) && hot->owns(w.bz) && hot->owns(w.step) && hot->owns(w.act) &&
                    hot->owns(w.bstg);
       w.band_wave = wave_mode && w.band_hot;
 #endif
+      } else w.H = nullptr;
     } else {
+      w.dn.on = false;
       if (p > C::PMAX) return ST_TOO_LARGE;
       // rc[d], theta[32] and dv[32] are the always-zero dummies of the lite index structures (cone_core.h)
       const uint32_t pg = pp < 33u ? 33u : pp;
@@ -256,7 +313,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       r = solve_cone_ipm(c, vv, w, max_iter);
       lite = true;  // (handled)
     }
-#if defined(__HIPCC__)
+#if defined(CAVE_GPU_CODE)
     if constexpr (!LARGE && C::LITE_OK) if (!lite) {
       // small +-1 cone: Newton iteration on ONE wave over the lite index structures (cone_core.h).  Carried by
       // the kernel shapes with a 256-register budget (one and two waves per instance: it wants ~200 VGPRs, and
@@ -558,7 +615,9 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
   uint64_t solve = 3 * align8u(8 * d) + align8u(4 * d)                                           // res, tvec/q, rc, wold
                    + 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p)  // theta..step, told, H, act, long rows
                    + 8 + 2 * 8 * 33;                                                              // dummy slots of the lite form
-  if (lite_room && pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)nnzM);
+  // (room for cones of up to 1024 non-zeros, the common case; a bigger cone takes the lite form when the arena
+  //  happens to have room left -- lite_build asks with try_get -- and the general solver otherwise)
+  if (lite_room && pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)(nnzM < 1024 ? nnzM : 1024));
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
@@ -622,6 +681,14 @@ static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int
 // needs, so that four workgroups fit a CU; otherwise a 4 KiB-rounded figure with room for a third row vector.
 static inline uint32_t packed_large_lds_bytes(int64_t max_rows, int64_t max_bw) {
   const uint64_t p = max_rows > 0 ? max_rows : 1, ld = (uint64_t)max_bw + 1u;
+  if (dense_shape((int)(p > 0x7fffffff ? 0x7fffffff : p), (int)max_bw)) {
+    // dense reduced systems (cone_dense.h): the folded matrix, its scratch, the Schur system of up to 32 bound rows,
+    // and the row vectors of the Newton iteration -- 72 KB at p = 105, so two workgroups share a CU
+    const uint64_t nI = p < (uint64_t)kDenseMaxBound ? p : (uint64_t)kDenseMaxBound;
+    uint64_t tot = dense_lds_bytes((int)p, (int)nI) + 64u + 9u * (8u * p + 8u) + p + 256u + 64u;
+    tot = (tot + 255u) & ~255ull;
+    if (tot <= kMaxLds) return (uint32_t)tot;
+  }
   if (band_wave_fits((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) {
     const uint64_t need = 8ull * (band_wave_window((int)max_bw) + 2ull * p + band_wave_staging((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) + p + 64u;
     const uint64_t tot = ((need + 256u + 64u) + 255u) & ~255ull;  // + context scratch, alignment slack
@@ -644,7 +711,8 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
   s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256 + 8 + 2 * 8 * 33;
   if (lite_room && all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
-    const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)max_nnz);
+    // (the lite form takes cones of up to 1024 non-zeros; a store may hold a few bigger ones, which run the general solver)
+    const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)(max_nnz < 1024 ? max_nnz : 1024));
     if (with_lite <= kMaxLds) s = with_lite;
   }
   if (s > kMaxLds) return -1;

@@ -39,7 +39,7 @@ struct SoloCtx {
   __device__ __forceinline__ int lane_id() const { return lane; }
   __device__ __forceinline__ double wave_sum(double v) const { return wave_sum_f64(v); }
   __device__ __forceinline__ double wave_max(double v) const { return wave_max_f64(v); }
-  __device__ __forceinline__ void sync() const { asm volatile("" ::: "memory"); }
+  __device__ __forceinline__ void sync() const { CAVE_WAVE_ORDER(); }
   __device__ __forceinline__ double reduce_sum(double v) const { return wave_sum_f64(v); }
   __device__ __forceinline__ void reduce_sum2(double& a, double& b) const { wave_reduce2_f64<false>(a, b); }
   __device__ __forceinline__ void reduce_sum_max(double& s, double& m) const { wave_reduce2_f64<true>(s, m); }
@@ -101,11 +101,9 @@ struct BlockCtx {
   // lane l gets lane l-1's value (lane 0: 0)
   __device__ __forceinline__ double wave_shift_up(double v) const { return dpp_f64<0x138, 0xf>(0.0, v); }  // wave_shr:1
   // barrier that orders LDS traffic only (typed ds_* accesses): does not wait for global loads / stores in flight
-  __device__ __forceinline__ void sync_lds() const {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
+  __device__ __forceinline__ void sync_lds() const { CAVE_LDS_BARRIER(); }
   // LDS-only form of wave_fence (ds operations of one wave execute in order)
-  __device__ __forceinline__ void wave_fence_lds() const { asm volatile("" ::: "memory"); }
+  __device__ __forceinline__ void wave_fence_lds() const { CAVE_WAVE_ORDER(); }
   // make this wave's earlier stores visible to its own later loads issued by other lanes
   __device__ __forceinline__ void wave_fence() const {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -163,6 +161,13 @@ struct BlockCtx {
   __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }
   __device__ __forceinline__ void atomic_add_f64_lds(typename SpacePtr<double, 3>::type p, double v) const {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_f64
+  }
+  // 64-bit integer add in LDS (fixed-point accumulation: associative, so the sum does not depend on the order)
+  __device__ __forceinline__ void atomic_add_i64_lds(typename SpacePtr<long long, 3>::type p, long long v) const {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u64
+  }
+  __device__ __forceinline__ void atomic_add_i64(long long* p, long long v) const {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
   }
 
   // publish this wave's count, return (sum over lower waves, total)

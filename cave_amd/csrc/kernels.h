@@ -69,11 +69,13 @@ __global__ CAVE_BOUNDS(C) void cone_pack_kernel(PackParams P) {
   const int64_t b = blockIdx.x;
 #ifdef CAVE_STAMPS
   for (int i = 0; i < 32; ++i) c.st[i] = 0;
-  unsigned long long mt0 = __builtin_amdgcn_s_memtime();
+  unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   if (b < P.B) run_pack_instance(c, smem, P, b);
 #ifdef CAVE_STAMPS
   c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
+  c.st[15] = rt0;                                // absolute start / end (100 MHz): launch skew across workgroups
+  c.st[9] = __builtin_amdgcn_s_memrealtime();
   if (c.tid() == 0 && b < 8192 && b < P.B) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
 #endif
 }
@@ -92,6 +94,7 @@ __global__ CAVE_BOUNDS(C) void cone_packed_kernel(PackedParams P) {
 #ifdef CAVE_STAMPS
   c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
   c.st[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
+  c.st[0] = rt0;                                      // absolute start
   if (c.tid() == 0 && b < 8192 && b < P.B) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = c.st[i];
 #endif
 }

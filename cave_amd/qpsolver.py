@@ -104,8 +104,8 @@ def fast_path_cannot_fit(d: int) -> bool:
 #             registers -- more than the 4-wave streaming shape can give without losing residency.
 # The two kernels each get the launch shape they need; the transient store costs ~10 KB of extra HBM traffic per
 # instance against 178 KB of dense input (TSP-20).  Instances beyond the slot capacity (more than 32 reduced
-# rows / 1024 non-zeros, or entries other than +-1) report TOO_LARGE and the batch falls back to the fused kernel.
-SPLIT_MAX_D, SPLIT_ROWS, SPLIT_NNZ = 256, 32, 1024
+# rows / 1536 non-zeros, or entries other than +-1) report TOO_LARGE and the batch falls back to the fused kernel.
+SPLIT_MAX_D, SPLIT_ROWS, SPLIT_NNZ = 256, 32, 1536
 _slot_stores: dict = {}
 _split_ok: dict[tuple[int, int], bool] = {}  # (m, d) -> the split form fitted every instance of a checked batch
 

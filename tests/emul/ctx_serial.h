@@ -37,6 +37,8 @@ struct SerialCtx {
   void atomic_or_u32(uint32_t* p, uint32_t v) const { *p |= v; }
   void atomic_add_f64(double* p, double v) const { *p += v; }
   void atomic_add_f64_lds(double* p, double v) const { *p += v; }
+  void atomic_add_i64_lds(long long* p, long long v) const { *p += v; }
+  void atomic_add_i64(long long* p, long long v) const { *p += v; }
   uint32_t exclusive_scan_u32(uint32_t* a, int n) const {
     uint32_t run = 0;
     for (int i = 0; i < n; ++i) { uint32_t v = a[i]; a[i] = run; run += v; }

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <vector>
 
+#define CAVE_EMUL_COUNTERS 1
 #include "ctx_serial.h"
 #include "../../cave_amd/csrc/cone_core.h"
 #include "../../cave_amd/csrc/cone_instance.h"
@@ -13,6 +14,11 @@
 using namespace cave;
 
 extern "C" {
+
+// how many instances took which path since the last call ([0] dense LDL^T of the large-cone path, ...); resets
+void cave_emul_path_counters(long* out) {
+  for (int i = 0; i < 8; ++i) { out[i] = emul_counters()[i]; emul_counters()[i] = 0; }
+}
 
 int32_t cave_emul_default_limits(int64_t m_max, int64_t d, int32_t* nnz_cap, int32_t* lds_bytes) {
   return default_limits(m_max, d, nnz_cap, lds_bytes);

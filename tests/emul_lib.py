@@ -19,6 +19,7 @@ _SRC = os.path.join(_HERE, "emul", "emul_abi.cpp")
 _DEPS = [
     _SRC,
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_band.h"),
+    os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_dense.h"),
     os.path.join(_HERE, "emul", "ctx_serial.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_core.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_common.h"),
@@ -57,6 +58,12 @@ def _p(a):
 class Emul:
     def __init__(self, asan: bool = False):
         self.lib = C.CDLL(build(asan))
+
+    def path_counters(self):
+        """[dense-LDL^T instances, ...] since the last call (tests assert that a case took the path it is meant for)."""
+        out = (C.c_long * 8)()
+        self.lib.cave_emul_path_counters(out)
+        return list(out)
 
     def cone_dense(self, ctrs, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0, nnz_cap=0, lds_bytes=0):
         ctrs = np.ascontiguousarray(ctrs, dtype=np.float32)

@@ -66,6 +66,7 @@ def test_prepared_form_from_the_first_step_and_beyond_the_pool():
     from cave_amd.qpsolver import PREP_POOL, PreparedCones, cone_op_dense, cone_op_prepared, prepare_dense, stream_mark
 
     ctrs, costs, _ = synth.tsp_batch(20, 96, seed=21)
+    qpsolver.forget_shape(ctrs.shape[1], ctrs.shape[2])  # whatever earlier tests concluded about this (m_max, d)
     rng = np.random.default_rng(8)
     batches = [(torch.tensor(ctrs[rng.permutation(96)[:40]], device="cuda"),
                 torch.tensor(costs[:40] + rng.normal(0, 0.1, (40, costs.shape[1])).astype(np.float32), device="cuda"))

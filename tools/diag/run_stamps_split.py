@@ -26,6 +26,13 @@ print(f"pack kernel (4 waves, slot mode): {mean[14]:.0f} cycles per instance (ma
 for i, n in [(10, "scan (HBM stream + compaction)"), (0, "scan_and_build total"), (11, "  classify rows"), (12, "  pairing"),
              (13, "  var list + CSR/CSC"), (1, "avg + store writes")]:
     print(f"  {n:40s} {mean[i]:10.0f}  {100 * mean[i] / mean[14]:5.1f}%")
+t0 = a[:, 15].min()
+st, en = (a[:, 15] - t0) / 100.0, (a[:, 9] - t0) / 100.0
+q = [0, 50, 90, 99, 100]
+print(f"  workgroup start (us after the first) quantiles {q}: {np.percentile(st, q).round(1).tolist()}")
+print(f"  workgroup end   (us after the first start)         : {np.percentile(en, q).round(1).tolist()}")
+print(f"  scan cycles quantiles: {np.percentile(a[:, 10], q).round().tolist()}; total cycles: {np.percentile(a[:, 14], q).round().tolist()}")
+print(f"  clock: {np.median(a[:, 14] / np.maximum((a[:, 9] - a[:, 15]), 1) / 10):.3f} GHz (cycles / memrealtime)")
 out = {k: torch.empty((B,) if k == "loss" else (B, d), dtype=torch.float32, device="cuda") for k in ("loss", "grad")}
 status = torch.empty(B, dtype=torch.int32, device="cuda"); iters = torch.empty(B, dtype=torch.int32, device="cuda")
 for _ in range(3):
@@ -45,3 +52,11 @@ print(f"  Newton loop cycles per iteration: mean {np.mean(solve / np.maximum(it,
 w = int(a[:, 14].argmax())
 print(f"  worst instance: {a[w,14]:.0f} cycles, {it[w]:.0f} iterations; quantiles of total cycles 50/90/99/100: "
       f"{np.percentile(a[:,14], [50, 90, 99, 100]).round().tolist()}")
+order = np.argsort(-a[:, 14])[:10]
+print("  slowest instances (cycles, iters, then per-phase grad/hess/inner/GJ/ls-setup/ls-loop/resid, outside-loop):")
+for i in order:
+    ph = a[i, 2:9]
+    print(f"    {a[i,14]:8.0f} it {it[i]:2.0f}  " + " ".join(f"{x:7.0f}" for x in ph) + f"  out {a[i,14] - ph.sum():7.0f}  GJ/iter {a[i,5]/max(it[i],1):6.0f}")
+t0 = a[:, 0].min()
+st = (a[:, 0] - t0) / 100.0
+print(f"  solve workgroup start quantiles {q} (us): {np.percentile(st, q).round(1).tolist()}; end: {np.percentile(st + a[:,15]/100.0, q).round(1).tolist()}")

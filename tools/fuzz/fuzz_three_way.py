@@ -80,4 +80,5 @@ while time.time()-t0 < T:
                     bad_scipy += 1; by_kind[kind]=by_kind.get(kind,0)+1
             except RuntimeError: scipy_err += 1
 print(f"oracle hit its cap on {globals().get('oracle_raised', 0)} batches; " if globals().get("oracle_raised") else "", end="")
+print("path counters [dense-LDL^T, ...]:", E.path_counters())
 print(f"n {n}  ours!=oracle {bad_ours}  scipy!=oracle {bad_scipy} (by kind {by_kind}) scipy raised {scipy_err}  worst ours-oracle {worst:.2e} max iters {itmax}")
