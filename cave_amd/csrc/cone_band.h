@@ -701,6 +701,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         if (cpos >= CH) {  // into chunk cidx + 1: chunk cidx + 2 (registers) takes the buffer chunk cidx has left
           cpos -= CH;
           ++cidx;
+          CAVE_WAVE_ORDER();  // ... once every lane has read its last rows out of that buffer
           park((cidx + 1) & 1);
           fetch(Hb, (R + (cidx + 2) * CH) * ld, p * ld);
         }
@@ -790,6 +791,9 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
 #pragma unroll
       for (int a = 0; a < NB; ++a) zqv[a] = scrQ[a * ncol + NB + (lane < bw ? lane : 0)];
       double zz = z[zown ? k + NB + lane : 0];
+      // every load of the step precedes its stores -- in every lane: a lane past the end of a round repeats another
+      // lane's duo and must read what that lane read, not what it has already written back
+      CAVE_WAVE_ORDER();
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
 #pragma unroll

@@ -374,9 +374,11 @@ CAVE_NOINLINE bool dense_model_step(C& c, const SolveView& v, const DenseWork& d
   auto ss = space_cast<3>(dw.ss);
   auto sr = space_cast<3>(dw.sr);
   auto sact = space_cast<3>(dw.sact);
+  CAVE_T0();
   for (int q = c.tid(); q < p; q += NT) z[q] = -g[ord[q]];
   c.sync();
   dense_factor(c, dw, p, reg_rel);
+  CAVE_ACC(11);
   // Schur complement of the bound rows as a full square (the register solver reads rows)
   for (int idx = c.tid(); idx < nI * nI; idx += NT) {
     const int i = idx / nI, j = idx - i * nI;
@@ -449,7 +451,9 @@ CAVE_NOINLINE bool dense_model_step(C& c, const SolveView& v, const DenseWork& d
     }
     for (int i = c.tid(); i < nI; i += NT) x[nF + i] = st[i] - theta[ord[nF + i]];
     c.sync();
+    CAVE_ACC(10);
     dense_backsub(c, dw, p);
+    CAVE_ACC(12);
     double mv = 0.0;
     for (int q = c.tid(); q < p; q += NT) {
       const int row = ord[q];

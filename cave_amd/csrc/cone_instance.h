@@ -269,6 +269,9 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.band_hot = hot && hot->owns(w.bwin) && hot->owns(w.bz) && hot->owns(w.step) && hot->owns(w.act) &&
                    hot->owns(w.bstg);
       w.band_wave = wave_mode && w.band_hot;
+#ifdef CAVE_EMUL_COUNTERS
+      if (c.tid() == 0 && w.band_wave) ++emul_counters()[1];
+#endif
 #endif
       } else w.H = nullptr;
     } else {
@@ -324,6 +327,9 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       LiteCone L;
       lite = gridDim.x <= 2048u && lite_build(c, ar, vv, L);
       if (lite) {
+#ifdef CAVE_EMUL_COUNTERS
+        if (c.tid() == 0) ++emul_counters()[2];
+#endif
         r.f = 0.0; r.iters = 0; r.status = ST_OK;
         if (c.wave_id() == 0) {
           SoloCtx<32, 4> sc;

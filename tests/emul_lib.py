@@ -202,3 +202,107 @@ class Emul:
             _p(out["status"]), _p(out["iters"]))
         assert rc == 0, rc
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SIMT emulation build (tests/emul/simt_abi.cpp): the GPU-only code paths -- wave contexts, DPP / readlane /
+# ballot primitives, the one-wave lite solver, the one-/two-wave band elimination, the blocked dense LDL^T --
+# compiled by g++ against a shim <hip/hip_runtime.h> in which every lane is a fiber.  TEST INFRASTRUCTURE ONLY.
+_SIMT_SRC = os.path.join(_HERE, "emul", "simt_abi.cpp")
+_SIMT_DEPS = _DEPS + [_SIMT_SRC, os.path.join(_HERE, "emul", "simt", "hip", "hip_runtime.h")] + [
+    os.path.join(_HERE, "..", "cave_amd", "csrc", n) for n in ("wave_prims.h", "ctx_wave.h", "ctx_block.h")]
+
+
+def build_simt(asan: bool = False) -> str:
+    out = os.path.join(_HERE, "emul", "_simt_asan.so" if asan else "_simt.so")
+    newest = max(os.path.getmtime(p) for p in _SIMT_DEPS)
+    if os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-I" + os.path.join(_HERE, "emul", "simt"), _SIMT_SRC,
+           "-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+class Simt:
+    """Runs the kernels' per-instance code with their real workgroup shapes (1 / 2 / 4 waves of 64 lanes).
+    Stores come from Emul.pack / Emul.pack_large (host arrays).  `seed` != 0 shuffles the order in which the lanes
+    run between two rendezvous (a hand-over the source does not order then shows up as wrong numbers)."""
+
+    def __init__(self, asan: bool = False):
+        self.lib = C.CDLL(build_simt(asan))
+        self.lib.cave_simt_packed_large_slice_bytes.restype = C.c_int64
+
+    def path_counters(self):
+        out = (C.c_long * 8)()
+        self.lib.cave_simt_path_counters(out)
+        return list(out)
+
+    def _outs(self, B, d):
+        return {
+            "proj": np.zeros((B, d), np.float32), "rnorm": np.zeros(B, np.float32),
+            "target": np.zeros((B, d), np.float32), "loss": np.zeros(B, np.float32),
+            "grad": np.zeros((B, d), np.float32), "status": np.zeros(B, np.int32),
+            "iters": np.zeros(B, np.int32),
+        }
+
+    def cone_dense(self, ctrs, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0, waves=1, seed=0):
+        ctrs = np.ascontiguousarray(ctrs, dtype=np.float32)
+        B, m, d = ctrs.shape
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        out = self._outs(B, d)
+        rc = self.lib.cave_simt_cone_dense(
+            _p(ctrs), _p(pred), C.c_int64(B), C.c_int64(m), C.c_int64(d), C.c_int32(mode), C.c_float(sign),
+            C.c_float(inner_ratio), C.c_int32(max_iter), C.c_int32(0), C.c_int32(0), C.c_int32(waves), C.c_uint64(seed),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
+
+    def cone_packed(self, store, arrs, max_rows, max_nnz, ids, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0,
+                    waves=1, seed=0):
+        d = store.d
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        B = len(ids)
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        all_pm1 = int(bool((arrs["flags"] & 1).all()))
+        lds = self.lib.cave_simt_packed_lds_bytes(C.c_int64(d), C.c_int32(max_rows), C.c_int32(max_nnz), C.c_int32(all_pm1))
+        assert lds > 0
+        out = self._outs(B, d)
+        rc = self.lib.cave_simt_cone_packed(
+            C.byref(store), _p(ids), _p(pred), C.c_int64(B), C.c_int32(mode), C.c_float(sign), C.c_float(inner_ratio),
+            C.c_int32(max_iter), C.c_int32(lds), C.c_int32(waves), C.c_uint64(seed),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
+
+    def cone_packed_large(self, store, arrs, max_rows, max_bw, ids, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0,
+                          waves=2, seed=0, lds_bytes=0):
+        d = store.d
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        B = len(ids)
+        pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
+        band = max_rows * (max_bw + 1)
+        slice_bytes = int(self.lib.cave_simt_packed_large_slice_bytes(C.c_int64(d), C.c_int64(max_rows), C.c_int64(band)))
+        lds = lds_bytes or int(self.lib.cave_simt_packed_large_lds_bytes(C.c_int32(max_rows), C.c_int32(max_bw)))
+        out = self._outs(B, d)
+        rc = self.lib.cave_simt_cone_packed_large(
+            C.byref(store), _p(ids), _p(pred), C.c_int64(B), C.c_int32(mode), C.c_float(sign), C.c_float(inner_ratio),
+            C.c_int32(max_iter), C.c_int32(lds), C.c_int32(waves), C.c_int64(slice_bytes), C.c_uint64(seed),
+            _p(out["proj"]), _p(out["rnorm"]), _p(out["target"]), _p(out["loss"]), _p(out["grad"]),
+            _p(out["status"]), _p(out["iters"]))
+        assert rc == 0, rc
+        return out
+
+
+def store_bandwidth(arrs, B, d):
+    """max over instances of the half bandwidth of M M^T in the stored row order (as ConeStore._max_band_entries)."""
+    bw = 0
+    for b in range(B):
+        cp = arrs["cptr"][b * (d + 1):(b + 1) * (d + 1)].astype(np.int64) + int(arrs["nnz_off"][b])
+        for k in range(d):
+            if cp[k + 1] > cp[k] + 1:
+                bw = max(bw, int(arrs["cvar"][cp[k + 1] - 1]) - int(arrs["cvar"][cp[k]]))
+    return bw
