@@ -425,7 +425,9 @@ CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double
 // g = -M rc.  Rows are shared by TEAM adjacent lanes (fixed reduction tree); rows longer than
 // kLongRow entries are summed by one whole wave each.
 
-template <class C, bool PM1>
+template <class C, bool PM1> CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double* rc, double* g);
+
+template <class C, bool PM1, bool STREAMED = false>
 CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
   constexpr int TEAM = C::TEAM;
   constexpr int RPP = C::NT / TEAM;  // rows per pass
@@ -447,6 +449,8 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
     part = c.team_reduce_sum(part);
     if (valid && !is_long && sub == 0) g[i] = part;
   }
+  if constexpr (STREAMED && C::WL > 1) gradient_long_rows_streamed<C, PM1>(c, v, rc, g);
+  else
   for (int li = c.wave_id(); li < v.nlong; li += C::NWAVES) {  // one wave per long row
     const int i = (int)v.longrow[li];
     const uint32_t lo = v.mptr[i], hi = v.mptr[i + 1];
@@ -748,19 +752,115 @@ namespace cave {
 template <class C, class = void> struct ctx_lite : std::false_type {};
 template <class C> struct ctx_lite<C, std::void_t<decltype(C::LITE)>> : std::bool_constant<C::LITE> {};
 
+// ---- large-cone path: the cone is read from GLOBAL memory (the packed store or the workspace), every dependent load
+// costs a memory latency, so the loops below request the operands of several rows / columns before using any.
+// Long rows of g = -M rc (more than kLongRow entries: TSP degree rows, cut rows): one wave per row, U chunks of 64
+// entries in flight, two rows at a time (TSP-100: a 99-entry degree row takes one step, a 4700-entry cut row 19
+// steps instead of 74 dependent ones); fixed summation order.  (Short rows keep the 4-lanes-per-row loop of gradient().)
 template <class C, bool PM1>
+CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double* rc, double* g) {
+  constexpr int U = 4, WL = C::WL, NW = C::NWAVES;
+  const int lane = c.lane_id();
+  const uint32_t last = v.mptr[v.p] > 0u ? v.mptr[v.p] - 1u : 0u;
+  for (int l0 = c.wave_id(); l0 < v.nlong; l0 += 2 * NW) {
+    const int l1 = l0 + NW;
+    const bool two = l1 < v.nlong;
+    const int i0 = (int)v.longrow[l0], i1 = two ? (int)v.longrow[l1] : i0;
+    const uint32_t lo0 = v.mptr[i0], n0 = v.mptr[i0 + 1] - lo0;
+    const uint32_t lo1 = v.mptr[i1], n1 = two ? v.mptr[i1 + 1] - lo1 : 0u;
+    double part0 = 0.0, part1 = 0.0;
+    for (uint32_t off = 0; off < n0 || off < n1; off += (uint32_t)(U * WL)) {
+      uint32_t col[2][U];
+      double val[2][U], x[2][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t t = off + (uint32_t)(u * WL + lane);
+        const uint32_t e0 = lo0 + t < last ? lo0 + t : last, e1 = lo1 + t < last ? lo1 + t : last;  // clamped, unconditional
+        csr_entry<PM1>(v, e0, col[0][u], val[0][u]);
+        csr_entry<PM1>(v, e1, col[1][u], val[1][u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { x[0][u] = rc[col[0][u]]; x[1][u] = rc[col[1][u]]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t t = off + (uint32_t)(u * WL + lane);
+        part0 -= t < n0 ? val[0][u] * x[0][u] : 0.0;
+        part1 -= t < n1 ? val[1][u] * x[1][u] : 0.0;
+      }
+    }
+    part0 = c.wave_sum(part0);
+    part1 = c.wave_sum(part1);
+    if (lane == 0) {
+      g[i0] = part0;
+      if (two) g[i1] = part1;
+    }
+  }
+}
+
+// out[k] = base[k] + sgn * (M^T th)[k], G columns per thread at a time (extents, then entries, then operands)
+template <class C, bool PM1>
+CAVE_HD void gather_mt_streamed(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
+  constexpr int G = 4, E = 3, NT = C::NT;
+  const int d = v.d;
+  const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
+  for (int k0 = c.tid(); k0 < d; k0 += G * NT) {
+    uint32_t lo[G], cnt[G], a[G][E];
+    double x[G][E], t[G][E], r[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int k = k0 + u * NT;
+      const bool in = k < d;
+      const int kc = in ? k : d - 1;
+      lo[u] = v.cptr[kc];
+      cnt[u] = in ? v.cptr[kc + 1] - lo[u] : 0u;
+      r[u] = base ? (double)base[kc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t ee = lo[u] + (uint32_t)e < last ? lo[u] + (uint32_t)e : last;
+        csc_entry<PM1>(v, ee, a[u][e], x[u][e]);
+      }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int e = 0; e < E; ++e) t[u][e] = th[a[u][e]];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int k = k0 + u * NT;
+      if (k >= d) continue;
+      double acc = r[u];
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if ((uint32_t)e < cnt[u]) acc += sgn * x[u][e] * t[u][e];
+      for (uint32_t e = (uint32_t)E; e < cnt[u]; ++e) {  // columns with more than E entries
+        uint32_t var;
+        double val;
+        csc_entry<PM1>(v, lo[u] + e, var, val);
+        acc += sgn * val * th[var];
+      }
+      out[k] = acc;
+    }
+  }
+  c.sync();
+}
+
+// STREAMED: the large-cone path (cone arrays in global memory)
+template <class C, bool PM1, bool STREAMED = false>
 CAVE_HD void gradient_any(C& c, const SolveView& v, const double* rc, double* g) {
 #if defined(CAVE_GPU_CODE)
   if constexpr (ctx_lite<C>::value) { lite_gradient(c, c.lite, v.p, rc, g); return; }
 #endif
-  gradient<C, PM1>(c, v, rc, g);
+  gradient<C, PM1, STREAMED>(c, v, rc, g);
 }
-template <class C, bool PM1>
+template <class C, bool PM1, bool STREAMED = false>
 CAVE_HD void gather_any(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
 #if defined(CAVE_GPU_CODE)
   if constexpr (ctx_lite<C>::value) { lite_gather(c, c.lite, v.d, base, th, sgn, out); return; }
 #endif
-  gather_mt<C, PM1>(c, v, base, th, sgn, out);
+  if constexpr (STREAMED && C::WL > 1) gather_mt_streamed<C, PM1>(c, v, base, th, sgn, out);
+  else gather_mt<C, PM1>(c, v, base, th, sgn, out);
 }
 
 // One Newton step = exact minimisation of the local quadratic model over the
@@ -811,11 +911,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   if (warm && p > 0) {
     // the convergence test is relative to the projected gradient AT theta = 0 (what a cold start measures in its
     // first iteration), not at the warm point, where it is already small
-    gradient_any<C, PM1>(c, v, rc, w.g);
+    gradient_any<C, PM1, BAND>(c, v, rc, w.g);
     double gm = 0.0;
     for (int i = c.tid(); i < p; i += NT) gm = fmax(gm, fabs(v.vkind[i] ? w.g[i] : fmin(w.g[i], 0.0)));
     g0n = c.reduce_max(gm);
-    gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
+    gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
     f = refresh_clipped(c, v, r, rc);
   }
   const int ldh = w.ldh;
@@ -832,7 +932,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   for (; p > 0 && it < max_iter; ++it, cap07 *= CAVE_MU_CAP, sched01 *= CAVE_BMU_DECAY) {
     // gradient g = -M Pi(r) and projected-gradient norm
     CAVE_ACCF(22);
-    gradient_any<C, PM1>(c, v, rc, w.g);
+    gradient_any<C, PM1, BAND>(c, v, rc, w.g);
     CAVE_ACCF(16);
     // Zig-zag extrapolation.  On degenerate cones (duplicated generators, y inside the cone) the iteration can
     // settle into a two-cycle of active sets and crawl along a valley at a linear rate.  From iteration 10 on,
@@ -851,7 +951,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         amax = -c.reduce_max(-amax);
         c.sync();
         if (psi0 < 0.0 && amax > 0.0) {
-          gather_any<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
+          gather_any<C, PM1, BAND>(c, v, nullptr, w.dv, 1.0, w.q);
           const double alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
           for (int i = c.tid(); i < p; i += NT) {
             double t = theta[i] + alpha * w.dv[i];
@@ -859,9 +959,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
             theta[i] = t;
           }
           c.sync();
-          gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
+          gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
           f = refresh_clipped(c, v, r, rc);
-          gradient_any<C, PM1>(c, v, rc, w.g);
+          gradient_any<C, PM1, BAND>(c, v, rc, w.g);
         }
       }
       for (int i = c.tid(); i < p; i += NT) w.told[i] = theta[i];
@@ -1201,7 +1301,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       }
       update_theta(c, v, theta, tc, w.dv, alpha, amax);
       if (fresh) {
-        gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
+        gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
         fn = refresh_clipped(c, v, r, rc);
       } else {
         fn = 0.5 * c.reduce_sum(acc);
@@ -1209,12 +1309,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       }
       CAVE_ACC(8);
     } else {
-      gather_any<C, PM1>(c, v, nullptr, w.dv, 1.0, w.q);
+      gather_any<C, PM1, BAND>(c, v, nullptr, w.dv, 1.0, w.q);
       CAVE_ACC(6);
       alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
       update_theta(c, v, theta, tc, w.dv, alpha, amax);
       CAVE_ACC(7);
-      if ((it & 7) == 7) gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
+      if ((it & 7) == 7) gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
       else {
         for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
         c.sync();
@@ -1241,7 +1341,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   }
   // final residual straight from theta (the iteration updated r incrementally), clipped for the epilogue
   if (p > 0) {
-    gather_any<C, PM1>(c, v, w.y, theta, -1.0, r);
+    gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
     f = refresh_clipped(c, v, r, rc);
   }
   for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];

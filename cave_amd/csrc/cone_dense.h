@@ -108,21 +108,21 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, const double* r, doub
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     c.atomic_add_i64_lds(Aq + (fold_base(p, lo) + (hi - lo)), (long long)llrint(x * sc));
   };
-  // Every thread owns a contiguous block of columns (the threads of one instruction then work on columns far
-  // apart: different diagonal entries, no same-address serialisation), G columns at a time with the column extents
-  // and the first E entries of each requested together: the cone is read from global memory (the packed store or
-  // the workspace), one dependent load per entry would cost a full memory latency each.
+  // Consecutive lanes take consecutive columns (coalesced loads: the cone is read from global memory -- the packed
+  // store or the workspace), G columns per thread at a time with the column extents and the first E entries of each
+  // requested together: one dependent load per entry would cost a full memory latency each.  Lanes whose columns
+  // share a row (the edges of one TSP node) add to the same diagonal entry: the LDS serialises those adds (a few
+  // hundred cycles per instruction, measured cheaper than the 8x line requests of a blocked column assignment), and
+  // integer adds give the same sum in any order.
   constexpr int G = 4, E = 4;
-  const int per = (d + NT - 1) / NT;
-  const int k0 = c.tid() * per;
   const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
-  for (int u0 = 0; u0 < per; u0 += G) {
+  for (int kb = c.tid(); kb < d; kb += G * NT) {
     uint32_t lo[G], cnt[G], a[G][E];
     double wk[G], x[G][E];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      const int k = k0 + u0 + u;
-      const bool in = (u0 + u) < per && k < d;
+      const int k = kb + u * NT;
+      const bool in = k < d;
       const int kc = in ? k : d - 1;
       lo[u] = v.cptr[kc];
       cnt[u] = in ? v.cptr[kc + 1] - lo[u] : 0u;
@@ -217,7 +217,8 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
         for (int a = 0; a < NB; ++a) {
           const double dk = readlane_f64(u[a][0], a);
           const bool ok = (k0 + a < nF) && dk > 1e-300;
-          const double iv = ok ? 1.0 / dk : 0.0;
+          double iv = rcp_full(ok ? dk : 1.0);  // v_rcp_f64 + two Newton steps (a third of the IEEE divide)
+          iv = ok ? iv : 0.0;
           inv[a] = iv;
 #pragma unroll
           for (int b = a + 1; b < NB; ++b) {
@@ -261,26 +262,44 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
           p1[a] = scP[a * pc + t0 + 1];
           zq[a] = z[k0 + a < p ? k0 + a : p - 1];
         }
-        for (int r = cb + wave; r < p; r += NWV) {
-          double q[NB];
+        // RB trailing rows per pass, every load of the pass before its first store: rows are independent, and one
+        // row at a time each iteration waited out its own LDS round trips (12 k cycles per block step on TSP-100)
+        constexpr int RB = 4;
+        for (int rr = cb + wave; rr < p; rr += RB * NWV) {
+          double q[RB][NB], t0v[RB], t1v[RB];
+          int o[RB];
+          bool in0[RB], in1[RB];
 #pragma unroll
-          for (int a = 0; a < NB; ++a) q[a] = scQ[a * pc + (r - k0)];
-          const int o = fold_base(p, r) + (c0 - r);
-          const bool in0 = c0 >= r && c0 < p, in1 = c0 + 1 >= r && c0 + 1 < p;
-          double r0 = A[in0 ? o : 0], r1 = A[in1 ? o + 1 : 0];
+          for (int j = 0; j < RB; ++j) {
+            const int r = rr + j * NWV;
+            const int rc_ = r < p ? r : p - 1;
 #pragma unroll
-          for (int a = 0; a < NB; ++a) {
-            r0 = fma(-q[a], p0[a], r0);
-            r1 = fma(-q[a], p1[a], r1);
+            for (int a = 0; a < NB; ++a) q[j][a] = scQ[a * pc + (rc_ - k0)];
+            o[j] = fold_base(p, rc_) + (c0 - rc_);
+            in0[j] = r < p && c0 >= r && c0 < p;
+            in1[j] = r < p && c0 + 1 >= r && c0 + 1 < p;
+            t0v[j] = A[in0[j] ? o[j] : 0];
+            t1v[j] = A[in1[j] ? o[j] + 1 : 0];
           }
-          if (in0) A[o] = r0;
-          if (in1) A[o + 1] = r1;
-          if (lane == 63) {  // an idle lane of the triangle takes the right-hand side of this row
-            double zz = z[r];
 #pragma unroll
-            for (int a = 0; a < NB; ++a) zz = fma(-q[a], zq[a], zz);
-            z[r] = zz;
+          for (int j = 0; j < RB; ++j) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+              t0v[j] = fma(-q[j][a], p0[a], t0v[j]);
+              t1v[j] = fma(-q[j][a], p1[a], t1v[j]);
+            }
           }
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            if (in0[j]) A[o[j]] = t0v[j];
+            if (in1[j]) A[o[j] + 1] = t1v[j];
+          }
+        }
+        for (int r = cb + tid; r < p; r += NT) {  // the right-hand side below the block
+          double zz = z[r];
+#pragma unroll
+          for (int a = 0; a < NB; ++a) zz = fma(-scQ[a * pc + (r - k0)], zq[a], zz);
+          z[r] = zz;
         }
       }
       c.sync_lds();
