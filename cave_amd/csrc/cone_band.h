@@ -462,6 +462,18 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   CAVE_ACC(12);
 }
 
+// smoothed weight of coordinate k (see solve_cone_impl): derivative of the CHKS smoothing of the one-sided clip
+CAVE_HD double band_weight(uint8_t u, double rk, double mu) {
+  if (u == 0) return 1.0;
+  if (u == 3) return 0.0;
+  const double t = (u == 2) ? rk : -rk;  // > 0 on the side that carries residual
+  if (mu > 0.0) {
+    const double zz = t / mu;
+    return 0.5 * (1.0 + zz / sqrt(1.0 + zz * zz));
+  }
+  return (t > 0.0) ? 1.0 : 0.0;
+}
+
 // ---- sizing of the one-wave form below (shared with the host code: cone_instance.h, cave_hip.hip)
 constexpr int kBandBlock = 4;      // pivots eliminated per step
 constexpr int kBandWaveDuos = 5;   // duos per lane
@@ -530,6 +542,84 @@ __device__ __forceinline__ T* uniform_ptr(T* q) {  // arguments of a real call a
   return (T*)(((uint64_t)hi << 32) | lo);
 }
 
+// Rows first .. first + n - 1 (n <= 64: lane l builds row first + l) of H = M W M^T into LDS at dst, row stride
+// `stride` -- the band of a cone without bound rows is never materialised (BandGen, cone_common.h).  One lane owns one
+// row and adds its contributions in a fixed order: deterministic, no atomics.  The generator's fields are read once
+// into registers, the cone arrays are typed global pointers, and a row's entries are taken four at a time: their
+// coordinates' weights and column extents, then up to three entries of each column, are requested together -- three
+// dependent memory levels per batch instead of one per entry.  A REAL call: inlined into the elimination (which already
+// spills) the in-flight operands cost 2 ms on the 30x30 batch.
+CAVE_NOINLINE __device__ void band_gen_rows(const BandGen* gen_v, const int lane, const int p_v, const int bw_v,
+                                            const int first_v, const int n_v, double* dst_v, const int stride_v) {
+  const BandGen* gen = uniform_ptr(gen_v);
+  const int p = __builtin_amdgcn_readfirstlane(p_v), bw = __builtin_amdgcn_readfirstlane(bw_v);
+  const int first = __builtin_amdgcn_readfirstlane(first_v), n = __builtin_amdgcn_readfirstlane(n_v);
+  const int stride = __builtin_amdgcn_readfirstlane(stride_v);
+  auto dst = space_cast<3>(uniform_ptr(dst_v));
+  auto g_mptr = space_cast<1>(uniform_ptr(gen->mptr));
+  auto g_mcol = space_cast<1>(uniform_ptr(gen->mcol));
+  auto g_mval = space_cast<1>(uniform_ptr(gen->mval));
+  auto g_cptr = space_cast<1>(uniform_ptr(gen->cptr));
+  auto g_cvar = space_cast<1>(uniform_ptr(gen->cvar));
+  auto g_cvalc = space_cast<1>(uniform_ptr(gen->cvalc));
+  auto g_usign = space_cast<1>(uniform_ptr(gen->usign));
+  const double* g_r = uniform_ptr(gen->r);
+  const double g_mu = gen->mu;
+  const bool g_pm1 = gen->mval == nullptr;
+  if (lane >= n) return;
+  constexpr int EB = 4, CB = 3;
+  const int r = first + lane;
+  auto q = dst + lane * stride;
+  for (int t = 0; t < stride; ++t) q[t] = 0.0;
+  if (r >= p) return;
+  const uint32_t elo = g_mptr[r], ehi = g_mptr[r + 1];
+  const uint32_t elast = g_mptr[p] > 0u ? g_mptr[p] - 1u : 0u;
+  for (uint32_t eb = elo; eb < ehi; eb += (uint32_t)EB) {
+    uint32_t k[EB], clo[EB], cnt[EB], xj[EB][CB], us[EB];
+    double v1[EB], rk[EB], v2[EB][CB];
+#pragma unroll
+    for (int a = 0; a < EB; ++a) {
+      const uint32_t e = eb + (uint32_t)a < elast ? eb + (uint32_t)a : elast;  // clamped, unconditional
+      const uint32_t xk = g_mcol[e];
+      k[a] = g_pm1 ? (xk & 0x7fffu) : xk;
+      v1[a] = g_pm1 ? ((xk & 0x8000u) ? -1.0 : 1.0) : (double)g_mval[e];
+    }
+#pragma unroll
+    for (int a = 0; a < EB; ++a) {
+      us[a] = g_usign[k[a]];
+      rk[a] = g_r[k[a]];
+      clo[a] = g_cptr[k[a]];
+      cnt[a] = g_cptr[k[a] + 1u] - clo[a];
+    }
+#pragma unroll
+    for (int a = 0; a < EB; ++a)
+#pragma unroll
+      for (int b = 0; b < CB; ++b) {
+        const uint32_t e2 = clo[a] + (uint32_t)b < elast ? clo[a] + (uint32_t)b : elast;
+        xj[a][b] = g_cvar[e2];
+        v2[a][b] = g_pm1 ? 0.0 : (double)g_cvalc[e2];
+      }
+#pragma unroll
+    for (int a = 0; a < EB; ++a) {
+      if (eb + (uint32_t)a >= ehi) break;
+      const double tk = band_weight((uint8_t)us[a], rk[a], g_mu) * v1[a];
+#pragma unroll
+      for (int b = 0; b < CB; ++b) {
+        if ((uint32_t)b >= cnt[a]) break;
+        const int j = (int)(g_pm1 ? (xj[a][b] & 0x7fffu) : xj[a][b]);
+        const double vv = g_pm1 ? ((xj[a][b] & 0x8000u) ? -1.0 : 1.0) : v2[a][b];
+        if (j >= r && j - r <= bw) q[j - r] += tk * vv;
+      }
+      for (uint32_t b = (uint32_t)CB; b < cnt[a]; ++b) {  // columns with more than CB entries
+        const uint32_t x2 = g_cvar[clo[a] + b];
+        const int j = (int)(g_pm1 ? (x2 & 0x7fffu) : x2);
+        const double vv = g_pm1 ? ((x2 & 0x8000u) ? -1.0 : 1.0) : (double)g_cvalc[clo[a] + b];
+        if (j >= r && j - r <= bw) q[j - r] += tk * vv;
+      }
+    }
+  }
+}
+
 // The elimination advances kBandBlock = 4 pivots per step:
 //   A  the four pivot rows are read into registers (lane t = column k + t, lane 63 = the right-hand side) and
 //      eliminated against each other there (v_readlane broadcasts, no LDS traffic);
@@ -548,7 +638,8 @@ template <int NW>
 CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave_v, const double* Hb_v, const int bw_v,
                                                   const double* rhs_v, const uint8_t* act_v, const int p_v,
                                                   const double reg_rel, double* win_v, double* fac_v, double* z_v,
-                                                  double* x_v, double* stg_v, unsigned long long* stamps = nullptr) {
+                                                  double* x_v, double* stg_v, const BandGen* gen_v = nullptr,
+                                                  unsigned long long* stamps = nullptr) {
   constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs, NB = kBandBlock;
   constexpr int NWE = NW >= 2 ? 2 : 1;  // waves that share the elimination
   const int wave = __builtin_amdgcn_readfirstlane(wave_v);
@@ -571,6 +662,8 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   double* z_ = uniform_ptr(z_v);
   double* x_ = uniform_ptr(x_v);
   double* stg_ = uniform_ptr(stg_v);
+  const BandGen* gen = uniform_ptr(gen_v);
+  const bool hgen = gen != nullptr && gen->on;  // rows of H on demand (no bound rows): Hb is not read
 #ifdef CAVE_STAMPS
   struct { unsigned long long* st; } c{stamps};
 #endif
@@ -591,13 +684,20 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;
-  for (int i = lane; i < p; i += 64) {
-    if (!act[i]) md = fmax(md, Hb[i * ld]);
-    else nfix++;
-  }
-  md = wave_max_f64(md);
-  nfix = wave_sum_u32(nfix);
+  if (!hgen) {
+    for (int i = lane; i < p; i += 64) {
+      if (!act[i]) md = fmax(md, Hb[i * ld]);
+      else nfix++;
+    }
+    md = wave_max_f64(md);
+    nfix = wave_sum_u32(nfix);
+  } else md = gen->hdiag;
   const double reg = reg_rel * md;
+  // rows first .. first + n - 1 of H into dst (a real call: band_gen_rows has its own register allocation)
+  auto gen_rows = [&](const int first, const int n, decltype(win) dst, const int stride) __attribute__((always_inline)) {
+    band_gen_rows(gen, lane, p, bw, first, n, (double*)dst, stride);
+    CAVE_WAVE_ORDER();
+  };
   if (w0)
     for (int i = lane; i < p; i += 64) {
       double zi = rhs[i];
@@ -625,17 +725,28 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     }
   };
   // rows 0 .. R-1 of the band as the elimination sees them (rows past the end of the matrix are zero rows)
+  if (hgen) {
+    if (w0) {
+      gen_rows(0, R, win, wl);
+      if (lane < R && lane < p) win[lane * wl] += reg;
+    }
+  } else
   for (int idx = lane + 64 * wave; idx < wsz; idx += 64 * NWE) {
     const int r = idx / wl, t = idx - r * wl;
     win[idx] = (t <= bw) ? band_row_entry(Hb, ld, act, p, reg, r, t) : 0.0;
   }
   // chunk c = raw rows R + c*CH .. of H; chunk c is consumed from buffer c & 1 (the wave that admits rows stages them)
   if (wlast) {
-    fetch(Hb, R * ld, p * ld);
-    park(0);
-    fetch(Hb, (R + CH) * ld, p * ld);
-    park(1);
-    fetch(Hb, (R + 2 * CH) * ld, p * ld);
+    if (hgen) {
+      gen_rows(R, CH, stg, ld);
+      gen_rows(R + CH, CH, stg + csz, ld);
+    } else {
+      fetch(Hb, R * ld, p * ld);
+      park(0);
+      fetch(Hb, (R + CH) * ld, p * ld);
+      park(1);
+      fetch(Hb, (R + 2 * CH) * ld, p * ld);
+    }
   }
   // this wave's duos: duo q in row-major order over rows s = 1 .. bw below the block (entries t = s, s+2, ...);
   // round u = duos 64u .. 64u + 63, dealt to wave u % NWE.  A lane past the end of the last round repeats a duo of
@@ -702,8 +813,11 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
           cpos -= CH;
           ++cidx;
           CAVE_WAVE_ORDER();  // ... once every lane has read its last rows out of that buffer
-          park((cidx + 1) & 1);
-          fetch(Hb, (R + (cidx + 2) * CH) * ld, p * ld);
+          if (hgen) gen_rows(R + (cidx + 1) * CH, CH, stg + ((cidx + 1) & 1) * csz, ld);
+          else {
+            park((cidx + 1) & 1);
+            fetch(Hb, (R + (cidx + 2) * CH) * ld, p * ld);
+          }
         }
       };
     for (int k = 0; k < p; k += NB) {

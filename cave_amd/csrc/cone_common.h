@@ -160,6 +160,24 @@ struct SolveView {
   const uint32_t* longrow;  // ... and their indices
 };
 
+// Rows of H = M W M^T made on demand (one-wave band elimination of cones WITHOUT bound rows: grid shortest path).
+// The band is then never materialised: no zeroing, no atomics, no 8 p (bw + 1) bytes written and read back per
+// Newton iteration -- the elimination asks for a chunk of rows, one lane builds one row from the row's entries, the
+// smoothed weights of their coordinates and the columns of those coordinates, in a fixed order (deterministic).
+struct BandGen {
+  bool on;
+  const uint32_t* mptr;   // CSR of the reduced rows
+  const uint16_t* mcol;
+  const float* mval;      // null: entries are +-1, sign in bit 15 of mcol / cvar
+  const uint32_t* cptr;   // CSC
+  const uint16_t* cvar;
+  const float* cvalc;
+  const uint8_t* usign;
+  const double* r;        // unclipped residual of the current iterate
+  double mu;              // smoothing scale of this iteration
+  double hdiag;           // bound on the diagonal of H (largest squared row norm): scale of the Levenberg shift
+};
+
 // Dense reduced systems of the large-cone path (cone_dense.h): everything in LDS
 struct DenseWork {
   bool on;         // this instance takes the dense path
@@ -206,7 +224,9 @@ struct SolveWork {
   double* bz;      // [p] right-hand side being eliminated
   double* bstg;    // [2*bch*(bw+1)] staging buffers for rows streamed from / to the workspace
   int bch;         // rows per staged chunk
+  double hscale, hinv;  // fixed-point scale of the band Hessian's accumulation (large-cone path) and its reciprocal
   DenseWork dn;    // dense form (p <= bw + 1, p <= 128: TSP-100)
+  BandGen gen;     // band rows on demand (band_wave, no bound rows: grid shortest path)
 };
 
 struct SolveResult {

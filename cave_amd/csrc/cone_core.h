@@ -921,7 +921,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   const int ldh = w.ldh;
   bool dense_on = false;
   if constexpr (BAND) dense_on = w.dn.on;
-  if (!dense_on) for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+  bool hgen_on = false;
+  if constexpr (BAND) hgen_on = w.gen.on;
+  if (!dense_on && !hgen_on) for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
   if constexpr (!BAND) for (int k = c.tid(); k < d; k += NT) w.wold[k] = 0.f;
   c.sync();
   double reg_rel = 1e-12;  // Levenberg shift relative to max diag(H); raised when a step stalls
@@ -1007,7 +1009,10 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       mu = fmax(mu, CAVE_BMU_COEF * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
       auto weight = [&](int k) -> double { return band_weight(v.usign[k], r[k], mu); };
       if (dense_on) dense_hessian<C, PM1>(c, v, r, mu, w.dn);  // whole matrix in LDS, fixed point (cone_dense.h)
-      else {
+      else if (hgen_on) {  // no bound rows, one-wave elimination: it builds the rows it needs itself (cone_band.h)
+        w.gen.mu = mu;
+        w.gen.r = r;
+      } else {
       auto accumulate = [&](auto Hacc, auto add) {
         for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
         c.sync();
@@ -1056,13 +1061,26 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           }
         }
       };
+      // accumulated in 64-bit FIXED POINT (the zero bit pattern is shared with the doubles): integer adds are
+      // associative, so the sums -- and with them the whole projection -- do not depend on the order in which lanes
+      // and waves arrive; two launches give the same bits (the fp64 atomics spread results by 1e-7)
+      const double hsc = w.hscale, hiv = w.hinv;
       if (in_lds) {
         auto Hl = space_cast<3>(w.bwin);
-        accumulate(Hl, [&](decltype(Hl) q, double x) { c.atomic_add_f64_lds(q, x); });
+        accumulate(Hl, [&](decltype(Hl) q, double x) {
+          c.atomic_add_i64_lds(reinterpret_cast<typename SpacePtr<long long, 3>::type>(q), (long long)llrint(x * hsc));
+        });
         c.sync();
-        for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = Hl[idx];
+        auto Hq = reinterpret_cast<typename SpacePtr<long long, 3>::type>(Hl);
+        for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = (double)Hq[idx] * hiv;
       } else {
-        accumulate(w.H, [&](double* q, double x) { c.atomic_add_f64(q, x); });
+        accumulate(w.H, [&](double* q, double x) { c.atomic_add_i64(reinterpret_cast<long long*>(q), (long long)llrint(x * hsc)); });
+        c.sync();
+        long long* Hq = reinterpret_cast<long long*>(w.H);
+        for (int idx = c.tid(); idx < p * ldh; idx += NT) {
+          const long long qv = Hq[idx];
+          w.H[idx] = (double)qv * hiv;
+        }
       }
       }
     } else {
@@ -1153,7 +1171,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         if constexpr (BAND) {
 #if defined(CAVE_GPU_CODE)
           if (w.band_wave) {
-            solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg
+            solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg,
+                                           &w.gen
 #ifdef CAVE_STAMPS
                                   , c.st
 #endif

@@ -49,18 +49,6 @@ CAVE_HOSTDEV uint64_t dense_lds_bytes(int p, int nI) {
          4ull * (uint64_t)p + (uint64_t)nI + 128u;
 }
 
-// smoothed weight of coordinate k (see solve_cone_impl): derivative of the CHKS smoothing of the one-sided clip
-CAVE_HD double band_weight(uint8_t u, double rk, double mu) {
-  if (u == 0) return 1.0;
-  if (u == 3) return 0.0;
-  const double t = (u == 2) ? rk : -rk;  // > 0 on the side that carries residual
-  if (mu > 0.0) {
-    const double zz = t / mu;
-    return 0.5 * (1.0 + zz / sqrt(1.0 + zz * zz));
-  }
-  return (t > 0.0) ? 1.0 : 0.0;
-}
-
 // fixed-point scale for sums of products w * m_ak * m_bk, w in [0, 1]: |sum| <= vmax * rmax (largest entry times
 // largest row 1-norm) must stay below 2^61
 CAVE_HD double fixed_scale(double vmax, double rmax) {

@@ -183,6 +183,16 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       // Dense (or widely banded) reduced systems of up to 128 rows -- TSP-100 -- keep the whole matrix in LDS,
       // folded, and factor it once per Newton iteration (cone_dense.h).
       w.dn.on = false;
+      w.gen.on = false;
+      {  // fixed-point scale of the Hessian accumulation: |H_ab| <= (largest entry)^2 * (longest row)
+        double vm = v.pm1 ? 1.0 : 0.0, ml = 1.0;
+        if (!v.pm1) for (uint32_t e = c.tid(); e < v.mptr[p]; e += C::NT) vm = fmax(vm, fabs((double)v.mval[e]));
+        for (int i = c.tid(); i < p; i += C::NT) ml = fmax(ml, (double)(v.mptr[i + 1] - v.mptr[i]));
+        vm = c.reduce_max(vm);
+        ml = c.reduce_max(ml);
+        w.hscale = fixed_scale(vm, vm * ml);
+        w.hinv = 1.0 / w.hscale;
+      }
       if (hot && p >= 1 && dense_shape(p, bw)) {
         uint32_t cnt = 0;
         for (int i = c.tid(); i < p; i += C::NT) cnt += v.vkind[i] ? 0u : 1u;
@@ -208,14 +218,8 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
           if (dn.A && dn.dinv && dn.z && dn.x && dn.scr && dn.S && dn.sg && dn.st && dn.ss && dn.sr && dn.pos && dn.ord && dn.sact) {
             dn.on = true;
             dense_order(c, v, dn, tmp);
-            // fixed-point scale of the Hessian accumulation: |H_ab| <= (largest entry)^2 * (longest row)
-            double vm = v.pm1 ? 1.0 : 0.0, ml = 0.0;
-            if (!v.pm1) for (uint32_t e = c.tid(); e < v.mptr[p]; e += C::NT) vm = fmax(vm, fabs((double)v.mval[e]));
-            for (int i = c.tid(); i < p; i += C::NT) ml = fmax(ml, (double)(v.mptr[i + 1] - v.mptr[i]));
-            vm = c.reduce_max(vm);
-            ml = c.reduce_max(ml);
-            dn.hscale = fixed_scale(vm, vm * ml);
-            dn.hinv = 1.0 / dn.hscale;
+            dn.hscale = w.hscale;
+            dn.hinv = w.hinv;
 #ifdef CAVE_EMUL_COUNTERS
             if (c.tid() == 0) ++emul_counters()[0];  // test builds: how many instances took the dense path
 #endif
@@ -272,10 +276,41 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
 #ifdef CAVE_EMUL_COUNTERS
       if (c.tid() == 0 && w.band_wave) ++emul_counters()[1];
 #endif
+      // no row with a bound (grid shortest path: every reduced row is a +a/-a pair): the one-wave elimination builds
+      // the band rows it needs from the cone itself, the band is never written to memory (cone_band.h, BandGen)
+      if (w.band_wave) {
+        uint32_t nb = 0;
+        double hd = 0.0;
+        for (int i = c.tid(); i < p; i += C::NT) {
+          nb += v.vkind[i] ? 0u : 1u;
+          double s2 = 0.0;
+          for (uint32_t e = v.mptr[i]; e < v.mptr[i + 1]; ++e) {
+            const double val = v.pm1 ? 1.0 : (double)v.mval[e];
+            s2 += val * val;
+          }
+          hd = fmax(hd, s2);
+        }
+        nb = c.reduce_add_u32(nb);
+        hd = c.reduce_max(hd);
+#ifdef CAVE_NO_BAND_GEN  // (diagnostic builds: keep the materialised band)
+        nb = 1u;
+#endif
+        if (nb == 0u) {
+          BandGen& gn = w.gen;
+          gn.on = true;
+          gn.mptr = v.mptr; gn.mcol = v.mcol; gn.mval = v.pm1 ? nullptr : v.mval;
+          gn.cptr = v.cptr; gn.cvar = v.cvar; gn.cvalc = v.pm1 ? nullptr : v.cvalc;
+          gn.usign = v.usign; gn.r = nullptr; gn.mu = 0.0; gn.hdiag = hd;
+#ifdef CAVE_EMUL_COUNTERS
+          if (c.tid() == 0) ++emul_counters()[3];
+#endif
+        }
+      }
 #endif
       } else w.H = nullptr;
     } else {
       w.dn.on = false;
+      w.gen.on = false;
       if (p > C::PMAX) return ST_TOO_LARGE;
       // rc[d], theta[32] and dv[32] are the always-zero dummies of the lite index structures (cone_core.h)
       const uint32_t pg = pp < 33u ? 33u : pp;

@@ -185,3 +185,50 @@ def test_bench_force_dist_single_gpu():
     res = json.loads(line[-1])
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["process_group"]["world_size"] == 1
     assert res["sharded_packed_store"]["instances"] == 1024 and res["sharded_packed_store"]["projections_per_s"] > 0
+
+
+def _banded_inequality_cones(B, m, width, shift, seed, pairs=0):
+    from test_simt_emul import _banded_inequality_cones as gen
+
+    return gen(B, m, width, shift, seed, pairs)
+
+
+@pytest.mark.parametrize("kind", ["sp12", "sp30", "tsp100", "banded", "tsp70"])
+def test_large_path_two_launches_are_bit_identical(kind):
+    """the large-cone path accumulated its band Hessian with floating-point atomics (global memory, or
+    LDS for dense systems) and two launches on the same inputs differed by ~1e-7.  It now accumulates in 64-bit fixed
+    point (integer adds are associative), builds the rows of all-free narrow bands on demand in a fixed order, and
+    keeps dense systems in LDS: every output -- the iteration counts included -- must repeat bit for bit, at 4-, 2-
+    and 1-wave workgroups (ABI v8 `waves`), with other work on the GPU in between."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+
+    dev = torch.device("cuda")
+    if kind in ("sp12", "sp30", "tsp100", "tsp70"):
+        ckind, size, B, chunk = {"sp12": ("sp", (12, 12), 12, 12), "sp30": ("sp", (30, 30), 6, 6),
+                                 "tsp100": ("tsp", 100, 4, 2), "tsp70": ("tsp", 70, 6, 3)}[kind]
+        items, costs, _ = synth.coo_batch(ckind, size, B, seed=17)
+        d = int(costs.shape[1])
+        m_max = max(it[3] for it in items)
+        store = ConeStore.from_chunks_lazy(lambda i: synth.densify_on(items[i:i + chunk], d, dev, m_max),
+                                           list(range(0, B, chunk)))
+        pred, sign = torch.tensor(costs, device=dev), -1.0
+    else:
+        A, y = _banded_inequality_cones(6, 150, 7, 1, seed=5, pairs=6)
+        store = ConeStore.from_dense(torch.tensor(A, device=dev), chunk=6)
+        pred, sign, B = torch.tensor(y, device=dev), 1.0, 6
+    assert store.large
+    ids = torch.arange(B, device=dev)
+    big = torch.randn(2048, 2048, device=dev)
+    for waves in (4, 2, 1):
+        store.large_waves = waves
+        a = store.cone_op(ids, pred, MODE_INNER, sign, 0.2, outputs=ALL)
+        _ = big @ big  # other work in between: different arrival order of the workgroups
+        b = store.cone_op(ids.flip(0), pred.flip(0), MODE_INNER, sign, 0.2, outputs=ALL)  # another block -> instance map
+        c = store.cone_op(ids, pred, MODE_INNER, sign, 0.2, outputs=ALL)
+        assert bool((a["status"] == 0).all()), (kind, waves)
+        for k in ALL + ("iters",):
+            assert torch.equal(a[k], c[k]), (kind, waves, k)
+            assert torch.equal(a[k], b[k].flip(0)), (kind, waves, k, "flipped")

@@ -1,15 +1,23 @@
 #!/bin/bash
-# rocprofv3 passes for the large-cone kernels (configs 3 and 4, distinct cones); kernel trace and PMC in separate runs
-set -e
+# rocprofv3 passes for the large-cone kernels (configs 3 and 4, distinct cones); kernel trace and PMC in separate runs.
+#   WHICH="tsp100 sp30" PROF_TAG=r03 [CAVE_SO=variant.so] bash tools/diag/pmc_run_large.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for W in tsp100 sp30; do
-  OUT=$R/gpurun_out/prof_r02_$W
+for W in ${WHICH:-tsp100 sp30}; do
+  OUT=$R/gpurun_out/prof_${PROF_TAG:-r03}_$W
   mkdir -p $OUT
   CMD="python3 $R/tools/diag/large_profile.py $W"
-  timeout -k 10 250 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.txt 2> $OUT/trace.err || echo "trace failed"
-  timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.txt 2> $OUT/pmc_fetch.err || echo "pmc fetch failed"
-  timeout -k 10 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.txt 2> $OUT/pmc_write.err || echo "pmc write failed"
-  timeout -k 10 250 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.txt 2> $OUT/pmc_sq.err || echo "pmc sq failed"
-  tail -1 $OUT/trace.txt
+  pass() {
+    local name=$1; shift
+    timeout -k 10 250 rocprofv3 "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.txt 2> $OUT/$name.err
+    local rc=$?
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$W $name: KILLED at its time limit -- stopping"; exit 1; fi
+    [ $rc -ne 0 ] && echo "$W $name failed (rc $rc)"
+    return 0
+  }
+  pass trace --kernel-trace --stats
+  pass pmc_fetch --pmc FETCH_SIZE
+  pass pmc_write --pmc WRITE_SIZE
+  [ -z "$QUICK" ] && pass pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+  tail -2 $OUT/trace.txt
 done
