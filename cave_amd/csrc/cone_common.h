@@ -227,6 +227,11 @@ struct SolveWork {
   double hscale, hinv;  // fixed-point scale of the band Hessian's accumulation (large-cone path) and its reciprocal
   DenseWork dn;    // dense form (p <= bw + 1, p <= 128: TSP-100)
   BandGen gen;     // band rows on demand (band_wave, no bound rows: grid shortest path)
+  // lite solver with few bound rows (TSP-20: 20 free degree rows + <= 5 cut rows): partial elimination of the free
+  // rows + active-set loop on the Schur complement of the bound rows (cone_core.h lite_model_step)
+  bool ls_on;
+  int ls_nF, ls_nI;
+  double* ls_scr;  // LDS scratch: XS [p * nI], S [nI * (nI | 1)], four vectors of nI, flags
 };
 
 struct SolveResult {

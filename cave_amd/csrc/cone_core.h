@@ -474,31 +474,34 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
 // on one wave and on four.  The time goes into dependent LDS round trips (~70 cycles each: row pointer -> entry
 // -> operand, once per entry of a dynamic-length loop) and into instruction issue (~5 cycles per instruction
 // for a lone wave), not into barriers or arithmetic.  For cones with +-1 entries, at most 32 reduced rows, at
-// most 8 entries per column, at most 1024 non-zeros and d <= 256 the one-wave kernels therefore run the solver
+// most 8 entries per column, at most 1536 non-zeros and d <= 256 the one-wave kernels therefore run the solver
 // (SoloCtx, ctx_block.h) over two regular index structures built once per instance, in which every load of a
 // phase is independent of the others and NOTHING is predicated or branched on inside a phase:
 //   ell   [d][8] u16   the column of coordinate k: reduced row | sign << 15; unused slots hold row 32, a dummy
 //                      multiplier that is always 0 (ONE 16-byte LDS read per coordinate; M^T x, Hessian updates)
 //   csr16 [chn8 / 8][64][8] u16   CSR entry e = lane * chn8 + c: col | sign << 15; unused slots hold column d,
 //                      a dummy coordinate whose residual is always 0.  M x by PREFIX SUMS: each lane adds up its
-//                      contiguous run, a wave scan turns the lane totals into global prefixes P(e), and row i is
-//                      P(last entry of i) - P(last entry of i - 1): two LDS reads per row, no segment logic.
+//                      contiguous run, a wave scan of the lane totals gives the sum of the lanes before it, and row i
+//                      is P(last entry of i) - P(last entry of i - 1).  The LAST entry of a row carries the row in
+//                      bits 9..13 and a flag in bit 14: its lane stores the running sum under the row's number (every
+//                      other entry stores into the lane's dump slot: no predication), so the prefix table is 33 + 64
+//                      doubles instead of one per entry (8-12 KB: the room that lets cones of up to 1536 non-zeros in).
 struct LiteCone {
   const uint32_t* ell;    // [4 * d]            (16-byte aligned)
   const uint32_t* csr16;  // [4 * 64 * chn8 / 8 ... ] = 32 * chn8 words (16-byte aligned)
-  double* pfx;            // [64 * chn8 + 1 + 65] per-lane running sums, slot c * 64 + lane; slot 64 * chn8 stays 0; then
-                          //                    lbase[65]: sum of the lanes before lane l (lbase[64] = 0 goes with the zero slot)
-  const uint16_t* pend;   // [p + 1]            pend[i + 1]: slot of the last entry of row i (pend[0]: the zero slot)
-  int chn8;               // CSR entries per lane: 8 or 16
+  double* rs;             // [33 + 64 + 65]     rs[i]: running sum of its lane at the last entry of row i (rs[32] spare),
+                          //                    rs[33 + lane]: dump slots; then lbase[65]: sum of the lanes before lane l
+  const uint8_t* rl;      // [p]                lane that holds the last entry of row i
+  int chn8;               // CSR entries per lane: 8, 16 or 24
   int cmax;               // largest column count
 };
-static constexpr int kLiteMaxRows = 32, kLiteMaxD = 256, kLiteMaxCol = 8, kLiteMaxChunk = 16;
+static constexpr int kLiteMaxRows = 32, kLiteMaxD = 256, kLiteMaxCol = 8, kLiteMaxChunk = 24;
 static constexpr uint32_t kLiteDummyRow = 32;
 
-CAVE_HOSTDEV uint32_t lite_chunk(uint32_t nnz) { return nnz <= 512u ? 8u : 16u; }
+CAVE_HOSTDEV uint32_t lite_chunk(uint32_t nnz) { return nnz <= 512u ? 8u : (nnz <= 1024u ? 16u : 24u); }
 CAVE_HOSTDEV uint32_t lite_lds_bytes(int d, uint32_t nnz) {
   const uint32_t chn8 = lite_chunk(nnz);
-  return 16u * (uint32_t)d + 128u * chn8 + 8u * (64u * chn8 + 1u + 65u) + 2u * 34u + 64u;
+  return 16u * (uint32_t)d + 128u * chn8 + 8u * (33u + 64u + 65u) + 40u + 64u;
 }
 
 // Build the lite structures (all threads of the context).  Returns false when the cone does not qualify or the
@@ -513,9 +516,9 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
   const uint32_t chn8 = lite_chunk(nnz);
   uint32_t* ell = ar.try_get<uint32_t, 16u>(4u * (uint32_t)d);
   uint32_t* csr16 = ell ? ar.try_get<uint32_t, 16u>(32u * chn8) : nullptr;
-  double* pfx = csr16 ? ar.try_get<double>(64u * chn8 + 1u + 65u) : nullptr;
-  uint16_t* pend = pfx ? ar.try_get<uint16_t>(34u) : nullptr;
-  if (!pend) return false;
+  double* rs = csr16 ? ar.try_get<double>(33u + 64u + 65u) : nullptr;
+  uint8_t* rl = rs ? ar.try_get<uint8_t>(40u) : nullptr;
+  if (!rl) return false;
   // columns -> ELL rows of 8 (unused slots: the dummy row)
   uint32_t over = 0;
   double cm = 0.0;
@@ -540,22 +543,25 @@ CAVE_HD bool lite_build(C& c, Arena& ar, const SolveView& v, LiteCone& L) {
     const uint32_t x = v.mcol[e < nnz ? e : 0u];
     c16[idx] = (uint16_t)(e < nnz ? (x ^ 0x8000u) : (uint32_t)d);
   }
-  // where the prefix of each row's last entry will be found
-  for (int i = c.tid(); i <= p; i += NT) {
-    const uint32_t hi = v.mptr[i];  // one past the last entry of row i - 1
-    uint32_t slot = 64u * chn8;     // the zero slot: nothing before the first row
-    if (i > 0 && hi > 0u) {
-      const uint32_t e = hi - 1u;
-      slot = (e % chn8) * 64u + e / chn8;
-    }
-    pend[i] = (uint16_t)slot;
-  }
-  if (c.tid() == 0) { pfx[64u * chn8] = 0.0; pfx[64u * chn8 + 1u + 64u] = 0.0; }
   over = c.reduce_add_u32(over);
   L.cmax = (int)c.reduce_max(cm);
   c.sync();
-  if (over) return false;
-  L.ell = ell; L.csr16 = csr16; L.pfx = pfx; L.pend = pend; L.chn8 = (int)chn8;
+  // the last entry of every row: row number + flag into its index word, its lane into rl (rows are never empty: a
+  // reduced row has at least two entries)
+  uint32_t empty = 0;
+  for (int i = c.tid(); i < p; i += NT) {
+    const uint32_t lo = v.mptr[i], hi = v.mptr[i + 1];
+    if (hi <= lo) { empty = 1u; continue; }
+    const uint32_t e = hi - 1u, ln = e / chn8, cc = e - ln * chn8;
+    const uint32_t idx = ((cc / 8u) * 64u + ln) * 8u + (cc & 7u);
+    c16[idx] = (uint16_t)(c16[idx] | 0x4000u | ((uint32_t)i << 9));
+    rl[i] = (uint8_t)ln;
+  }
+  empty = c.reduce_add_u32(empty);
+  if (c.tid() == 0) rs[33u + 64u + 64u] = 0.0;
+  c.sync();
+  if (over || empty) return false;
+  L.ell = ell; L.csr16 = csr16; L.rs = rs; L.rl = rl; L.chn8 = (int)chn8;
   return true;
 }
 
@@ -596,14 +602,14 @@ __device__ __forceinline__ void lite_gather(C& c, const LiteCone& L, int d, cons
   c.sync();
 }
 
-// g = -M rc by prefix sums (rc[d] = 0 is the dummy coordinate).  Each lane stores the running sums of its own run
-// as it forms them; the sum of the lanes before it (one wave scan of the lane totals) goes to lbase[lane] and is
-// added when a row's two end points are read: (run + base) as before, so the bits are those of the form that kept
-// every running sum in registers until the scan was done -- which cost 2 VGPRs per entry of the run.
+// g = -M rc by prefix sums (rc[d] = 0 is the dummy coordinate).  Each lane forms the running sums of its own run and
+// stores the one at a row's last entry under the row's number; the sum of the lanes before it (one wave scan of the
+// lane totals) goes to lbase[lane] and is added when a row's two end points are read: (run + base) in a fixed order.
 template <class C>
 __device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, const double* rc, double* g) {
   const int lane = c.lane_id();
   double run = 0.0;
+  double* dump = L.rs + 33 + lane;
 #pragma unroll
   for (int g8 = 0; g8 < kLiteMaxChunk / 8; ++g8) {
     if (g8 * 8 < L.chn8) {  // wave-uniform; the loads of a group are all issued before the first add
@@ -611,21 +617,24 @@ __device__ __forceinline__ void lite_gradient(C& c, const LiteCone& L, int p, co
       const uint32_t w[4] = {t.x, t.y, t.z, t.w};
       double val[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) val[u] = rc[(w[u >> 1] >> ((u & 1) * 16)) & 0x7fffu];
+      for (int u = 0; u < 8; ++u) val[u] = rc[(w[u >> 1] >> ((u & 1) * 16)) & 0x1ffu];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        run += lite_signed(val[u], w[u >> 1] >> ((u & 1) * 16));
-        L.pfx[(g8 * 8 + u) * 64 + lane] = run;
+        const uint32_t x = w[u >> 1] >> ((u & 1) * 16);
+        run += lite_signed(val[u], x);
+        double* q = (x & 0x4000u) ? L.rs + ((x >> 9) & 31u) : dump;
+        *q = run;
       }
     }
   }
-  double* lbase = L.pfx + 64 * L.chn8 + 1;
+  double* lbase = L.rs + 33 + 64;
   lbase[lane] = wave_inclusive_scan_f64(run) - run;  // sum of the lanes before this one
   c.sync();
   if (lane < p) {
-    const uint32_t s1 = L.pend[lane + 1], s0 = L.pend[lane];
-    const uint32_t zs = 64u * (uint32_t)L.chn8;  // the zero slot pairs with lbase[64] = 0
-    g[lane] = (lbase[s1 == zs ? 64u : (s1 & 63u)] + L.pfx[s1]) - (lbase[s0 == zs ? 64u : (s0 & 63u)] + L.pfx[s0]);
+    const int l1 = L.rl[lane], l0 = L.rl[lane > 0 ? lane - 1 : 0];
+    const double hi = lbase[l1] + L.rs[lane];
+    const double lo = lane > 0 ? lbase[l0] + L.rs[lane - 1] : 0.0;
+    g[lane] = hi - lo;
   }
   c.sync();
 }
@@ -683,6 +692,105 @@ __device__ __forceinline__ void lite_hessian(C& c, const LiteCone& L, const Solv
       }
     });
   }
+}
+// Model minimisation of one Newton iteration for a lite cone whose rows are ordered [free | bound] with a few bound
+// rows (TSP-20: 20 degree equalities, then <= 5 subtour cuts with theta >= 0).  The register Gauss-Jordan eliminates
+// the free rows ONCE (gj_partial: pivots k < nF out of every row), which leaves the Schur complement S of the bound
+// rows and the reduced right-hand side; the active-set loop (ratio test, fix the blocking row, solve again) then runs
+// on S alone -- an nI x nI system, ~1 k cycles per round instead of ~9 k for the full elimination -- and the free rows
+// follow from x_F = x_g - X_I x_I.  The iterates of the bound rows are those of the full-space loop (the free rows are
+// at their optimum for every trial point either way).  Returns whether tc differs from theta.
+// This IS the model minimisation of the lite solver (cones with other row orders or more than 8 bound rows do not
+// take the lite form): the one-wave kernel sits at 250 VGPRs, and carrying this next to the full-elimination loop --
+// inlined or as a call -- spilled 32-80 VGPRs and made every instance slower.
+template <class C>
+__device__ __forceinline__ bool lite_model_step(C& c, const SolveView& v, SolveWork& w, const double* theta, double* tc,
+                                                double reg_rel) {
+  const int p = v.p, nF = w.ls_nF, nI = w.ls_nI, ldS = nI | 1, lane = c.lane_id();
+  double* XS = w.ls_scr;          // [p * nI]  rows < nF: X_I, rows >= nF: S
+  double* xg = w.step;            // [p]       rows < nF: x_g, rows >= nF: reduced right-hand side (idle otherwise)
+  double* S = XS + p * nI;        // [nI * ldS]
+  double* sg = S + nI * ldS;      // reduced model gradient at the working point
+  double* st = sg + nI;           // working point
+  double* ss = st + nI;           // step of one round
+  double* sr = ss + nI;           // right-hand side / S * step
+  uint8_t* sact = reinterpret_cast<uint8_t*>(sr + nI);
+  double* rhs = w.g2;
+  if (lane < p) rhs[lane] = -w.g[lane];
+  c.sync();
+  gj_partial<32, true>(lane, w.H, w.ldh, rhs, p, nF, reg_rel, XS, xg);
+  c.sync();
+  for (int idx = lane; idx < nI * nI; idx += 64) {
+    const int i = idx / nI, j = idx - i * nI;
+    S[i * ldS + j] = XS[(nF + i) * nI + j];
+  }
+  c.sync();
+  bool moved = false;
+  for (int attempt = 0; attempt < 2 && !moved; ++attempt) {
+    double gmin = 0.0;
+    if (attempt == 1) {
+      double gl = 0.0;
+      if (lane < nI && theta[nF + lane] <= 0.0) gl = fmin(gl, w.g[nF + lane]);
+      gmin = -c.reduce_max(-gl);
+      if (!(gmin < 0.0)) break;
+    }
+    if (lane < nI) {
+      const int row = nF + lane;
+      const bool at_bound = theta[row] <= 0.0;
+      const bool release = attempt == 0 ? (w.g[row] < 0.0) : (w.g[row] <= gmin);
+      sact[lane] = (uint8_t)((at_bound && !release) ? 1 : 0);
+      st[lane] = theta[row];
+      sg[lane] = -xg[row];
+    }
+    c.sync();
+    for (int inner = 0; inner <= nI; ++inner) {
+      if (lane < nI) sr[lane] = sact[lane] ? -st[lane] : -sg[lane];
+      c.sync();
+      c.solve_spd(S, ldS, sr, sact, nI, reg_rel, ss);
+      c.sync();
+      double amin = 2.0;
+      if (lane < nI && !sact[lane]) {
+        const double t = st[lane] + ss[lane];
+        if (t < 0.0) amin = fmin(amin, st[lane] / (st[lane] - t));
+      }
+      amin = -c.reduce_max(-amin);
+      const bool blocked = amin < 1.0;
+      const double a = blocked ? fmax(amin, 0.0) : 1.0;
+      double hs = 0.0;
+      if (blocked && lane < nI)
+        for (int j = 0; j < nI; ++j) hs += S[lane * ldS + j] * ss[j];
+      if (lane < nI) {
+        const double t = st[lane] + ss[lane];
+        double tn = st[lane] + a * ss[lane];
+        uint8_t act = sact[lane];
+        if (!act && blocked && t < 0.0 && st[lane] <= a * (st[lane] - t) * (1.0 + 1e-12)) {
+          tn = 0.0;
+          act = 1;
+        }
+        if (act) tn = 0.0;
+        c.sync();  // (every lane has read ss / st / sact of this round)
+        sact[lane] = act;
+        st[lane] = tn;
+        if (blocked) sg[lane] += a * hs;
+      } else c.sync();
+      c.sync();
+      if (!blocked) break;
+    }
+    double mv = 0.0;
+    if (lane < p) {
+      double t;
+      if (lane < nF) {
+        double x = xg[lane];
+        for (int j = 0; j < nI; ++j) x -= XS[lane * nI + j] * (st[j] - theta[nF + j]);
+        t = theta[lane] + x;
+      } else t = st[lane - nF];
+      tc[lane] = t;
+      mv = fabs(t - theta[lane]);
+    }
+    moved = c.reduce_max(mv) > 0.0;
+    c.sync();
+  }
+  return moved;
 }
 #endif  // CAVE_GPU_CODE
 
@@ -1139,6 +1247,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // ---- model minimisation over theta >= 0 (attempt 0: free every bound variable with
     //      a negative multiplier; attempt 1, only if that made no move: free the most negative one)
     bool moved = false;
+#if defined(CAVE_GPU_CODE)
+    // lite form: rows ordered [free | a few bound rows]: one elimination per iteration, active set on the Schur complement
+    if constexpr (ctx_lite<C>::value && !BAND) moved = lite_model_step(c, v, w, theta, tc, reg_rel);
+    else
+#endif
     if (dense_on) {
       // dense form: ONE factorisation of the rows without bounds, the active-set loop on the Schur complement of
       // the others (cone_dense.h)

@@ -166,6 +166,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     const uint32_t pp = (uint32_t)(p > 0 ? p : 1);
     SolveWork w;
     w.y = y;
+    w.ls_on = false;
     w.bw = 0; w.band_wave = false; w.bwin = nullptr; w.bfac = nullptr; w.bz = nullptr; w.bstg = nullptr; w.bch = 0; w.band_hot = false;
     if (mode == MODE_IPM) { warm_theta = nullptr; warm_state = nullptr; }  // the interior iterate is not a starting point
     // ONE thread reads the state byte and the workgroup agrees on it through a reduction: another workgroup
@@ -359,11 +360,30 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       // In the two-wave shape wave 1 helps with the scan and the build, then parks at the barrier below.
       // (A latency design: beyond ~2 instances per SIMD the general path's lower instruction count wins --
       //  packed TSP-20 at B = 4096: 374 us with the lite solver.)
+      // Eligible: rows ordered [free | 0 .. 8 bound rows] (TSP: degree equalities, then cuts; grid cones: no bound
+      // rows) and the epilogue's target scratch (idle while the solver runs) holds the reduced system -- the lite
+      // solver eliminates the free rows once per Newton iteration and runs its active-set loop on the Schur
+      // complement of the bound rows (lite_model_step).
+      bool ls_ok = false;
+      {
+        uint32_t nfree = 0, bad = 0;
+        for (int i = c.tid(); i < p; i += C::NT) nfree += v.vkind[i] ? 1u : 0u;
+        nfree = c.reduce_add_u32(nfree);
+        for (int i = c.tid(); i < p; i += C::NT) bad += ((v.vkind[i] != 0) != (i < (int)nfree)) ? 1u : 0u;
+        bad = c.reduce_add_u32(bad);
+        const int nI = p - (int)nfree;
+        const uint32_t need = (uint32_t)(p * nI + nI * (nI | 1) + 4 * nI + (nI + 7) / 8);
+        ls_ok = bad == 0u && nI <= 8 && need <= (uint32_t)d;
+        w.ls_on = ls_ok;
+        w.ls_nF = (int)nfree;
+        w.ls_nI = nI;
+        w.ls_scr = w.q;
+      }
       LiteCone L;
-      lite = gridDim.x <= 2048u && lite_build(c, ar, vv, L);
+      lite = gridDim.x <= 2048u && ls_ok && lite_build(c, ar, vv, L);
       if (lite) {
 #ifdef CAVE_EMUL_COUNTERS
-        if (c.tid() == 0) ++emul_counters()[2];
+        if (c.tid() == 0) { ++emul_counters()[2]; if (w.ls_nI > 0) ++emul_counters()[4]; }
 #endif
         r.f = 0.0; r.iters = 0; r.status = ST_OK;
         if (c.wave_id() == 0) {
@@ -656,9 +676,7 @@ static inline uint64_t arena_bytes_dense(int64_t m, int64_t d, int64_t cap, int6
   uint64_t solve = 3 * align8u(8 * d) + align8u(4 * d)                                           // res, tvec/q, rc, wold
                    + 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p)  // theta..step, told, H, act, long rows
                    + 8 + 2 * 8 * 33;                                                              // dummy slots of the lite form
-  // (room for cones of up to 1024 non-zeros, the common case; a bigger cone takes the lite form when the arena
-  //  happens to have room left -- lite_build asks with try_get -- and the general solver otherwise)
-  if (lite_room && pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)(nnzM < 1024 ? nnzM : 1024));
+  if (lite_room && pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) solve += lite_lds_bytes((int)d, (uint32_t)nnzM);
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
   return (build_peak > solve_peak ? build_peak : solve_peak) + 64 + 256;  // + context scratch
@@ -752,8 +770,7 @@ static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_
   s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
   s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256 + 8 + 2 * 8 * 33;
   if (lite_room && all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
-    // (the lite form takes cones of up to 1024 non-zeros; a store may hold a few bigger ones, which run the general solver)
-    const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)(max_nnz < 1024 ? max_nnz : 1024));
+    const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)max_nnz);
     if (with_lite <= kMaxLds) s = with_lite;
   }
   if (s > kMaxLds) return -1;

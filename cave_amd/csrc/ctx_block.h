@@ -47,10 +47,10 @@ struct SoloCtx {
   __device__ __forceinline__ uint32_t reduce_add_u32(uint32_t v) const { return wave_sum_u32(v); }
   __device__ __forceinline__ double team_reduce_sum(double v) const { return quad_sum_f64(v); }
   __device__ __forceinline__ void atomic_add_f64(double* p, double v) const { atomicAdd(p, v); }
-  // H holds its lower triangle only in the lite form
+  // the Schur system of the bound rows (lite_model_step, cone_core.h): at most 8 rows
   __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                             double reg_rel, double* dv) const {
-    gj_solve<(PMAX < 32 ? PMAX : 32), true>(lane, H, ldh, g, act, p, reg_rel, dv);
+    gj_solve_regs<8, true>(lane, H, ldh, g, act, p, reg_rel, dv);
   }
 };
 

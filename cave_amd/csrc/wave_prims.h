@@ -166,6 +166,79 @@ __device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh
   if (live) dv[lane] = ((deadmask >> lane) & 1ull) ? 0.0 : h[PM];
 }
 
+// PARTIAL Gauss-Jordan: only the pivots k < nF are eliminated, from every row, of [H + reg I | rhs] (no fixed rows).
+// With the rows ordered [F | I] the lanes then hold, in their columns j >= nF and the right-hand side:
+//   rows i <  nF:  X_I = H_FF^-1 H_FI  and  x_g = H_FF^-1 rhs_F        (the pivot rows are normalised)
+//   rows i >= nF:  S = H_II - H_IF H_FF^-1 H_FI  (Schur complement)  and  rhs_I - H_IF x_g
+// which go to XS[i * nI + (j - nF)] and xg[i] (LDS).  The active-set loop of a Newton step then works on S alone
+// and the rows of F follow by x_F = x_g - X_I x_I: one elimination per Newton iteration however many bounds block
+// (the slowest TSP-20 instances of a batch spent 100 k of 285 k cycles in repeated full eliminations).
+// A non-positive pivot drops its row as in gj_solve_regs (its X_I row and x_g entry are zero).
+template <int PM, bool LOWER = false, int G = 4>
+__device__ __forceinline__ void gj_partial_regs(int lane, const double* H, int ldh, const double* rhs, int p, int nF,
+                                                double reg_rel, double* XS, double* xg) {
+  const bool live = lane < p;
+  double diag0 = live ? H[lane * ldh + lane] : 0.0;
+  const double maxdiag = wave_max_f64(diag0);
+  const double reg = reg_rel * maxdiag;
+  double h[PM + 1];  // h[PM]: right-hand side
+#pragma unroll
+  for (int j = 0; j < PM; ++j) {
+    double v = 0.0;
+    if (j < p) {
+      if (live) v = (LOWER && j > lane) ? H[j * ldh + lane] : H[lane * ldh + j];
+      if (j == lane) v += reg;
+    } else if (j == lane) v = 1.0;  // rows beyond p: identity
+    h[j] = v;
+  }
+  h[PM] = live ? rhs[lane] : 0.0;
+  uint64_t deadmask = 0;
+  static_for<0, PM>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (k < nF) {
+      const double piv = readlane_f64(h[k], k);
+      const bool ok = piv > 1e-300;
+      const double pv = fmax(piv, 1e-300);
+      double inv = __builtin_amdgcn_rcp(pv);
+      inv = fma(fma(-pv, inv, 1.0), inv, inv);
+      deadmask |= ok ? 0ull : (1ull << k);
+      const double num = ok ? h[k] - ((lane == k) ? 1.0 : 0.0) : 0.0;
+      const double fac = num * inv;
+      constexpr int NCOL = PM - k;
+      static_for<0, (NCOL + G - 1) / G>([&](auto gc) {
+        constexpr int j0 = k + 1 + decltype(gc)::value * G;
+        double sv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (j0 + g <= PM) sv[g] = readlane_f64(h[j0 + g], k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (j0 + g <= PM) h[j0 + g] -= fac * sv[g];
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  });
+  const bool dead = ((deadmask >> lane) & 1ull) != 0ull;  // (only pivots k < nF can be flagged)
+  const int nI = p - nF;
+  if (live) xg[lane] = dead ? 0.0 : h[PM];
+  static_for<0, PM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (live && j >= nF && j < p) XS[lane * nI + (j - nF)] = dead ? 0.0 : h[j];
+  });
+}
+
+template <int PLIM, bool LOWER = false>
+__device__ __forceinline__ void gj_partial(int lane, const double* H, int ldh, const double* rhs, int p, int nF,
+                                           double reg_rel, double* XS, double* xg) {
+  if (p <= 8) gj_partial_regs<8, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if (p <= 16) gj_partial_regs<16, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if (p <= 20) gj_partial_regs<20, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if (p <= 24) gj_partial_regs<24, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if (p <= 28) gj_partial_regs<28, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if constexpr (PLIM >= 32) gj_partial_regs<32, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+}
+
 // The round-1 form of the same elimination: one column at a time (v_readlane pair, hazard nop, v_fma), explicit
 // diagonal.  ~20 % slower than gj_solve_regs but it needs fewer registers, which is what counts in the 4-wave
 // kernels (128-VGPR budget: with the batched form they spill ~70 registers).

@@ -190,8 +190,8 @@ class ConeStore:
         self.large_waves = 0  # large-cone path: waves per workgroup (1, 2, 4; 0 = the library's choice)
         self.all_pm1 = bool((t["flags"] & 1).all()) if N else False
         # every instance qualifies for the one-wave lite solver (cone_core.h: +-1 entries, <= 32 reduced rows,
-        # <= 1024 non-zeros, d <= 256; a few cones beyond 1024 non-zeros, or columns with more than 8 entries, fall back
-        # to the general solver inside the kernel)
+        # <= 1536 non-zeros, d <= 256, rows ordered [free | <= 8 bound rows]; a cone with a column of more than 8 entries
+        # or another row order falls back to the general solver inside the kernel)
         self.lite = self.all_pm1 and self.max_rows <= 32 and self.max_nnz <= 1536 and d <= 256
         self.lds_bytes = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, int(self.all_pm1)))
         # large batches (> 2048 instances) run the general solver: no room reserved for the lite structures
