@@ -212,7 +212,7 @@ int32_t cave_hip_cone_dense_large(const float* ctrs, const float* pred, int64_t 
                                   int32_t* iters, void* stream) {
   if (B < 0 || m_max < 0 || m_max > 65535 || d <= 0 || d > 65535 || m_max * d >= (int64_t)1 << 32)
     return fail(CAVE_E_INVALID, "cone_dense_large: bad shape (need m_max, d <= 65535, m_max*d < 2^32)");
-  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense_large: bad mode");
+  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_INNER_IPM) return fail(CAVE_E_INVALID, "cone_dense_large: bad mode");
   if (B == 0) return CAVE_OK;
   if (!ctrs && m_max > 0) return fail(CAVE_E_INVALID, "cone_dense_large: ctrs is null");
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_dense_large: pred is null");
@@ -221,7 +221,7 @@ int32_t cave_hip_cone_dense_large(const float* ctrs, const float* pred, int64_t 
   if (rc != CAVE_OK) return rc;
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
-  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
+  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100);
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   LargeWs W{(unsigned char*)workspace, (uint64_t)slice_bytes};
@@ -259,14 +259,14 @@ int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* 
                                    float* rnorm, float* target, float* loss, float* grad, int32_t* status,
                                    int32_t* iters, void* stream) {
   if (!store || B < 0) return fail(CAVE_E_INVALID, "cone_packed_large: null store / bad B");
-  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed_large: bad mode");
+  if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_INNER_IPM) return fail(CAVE_E_INVALID, "cone_packed_large: bad mode");
   if (B == 0) return CAVE_OK;
   if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_packed_large: pred is null");
   int32_t rc = check_large("cone_packed_large", workspace, slice_bytes, n_slots, lds_bytes);
   if (rc != CAVE_OK) return rc;
   PackedParams P;
   P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
-  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
+  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100); P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   LargeWs W{(unsigned char*)workspace, (uint64_t)slice_bytes};
   // workgroup shape (waves = 0): 4 waves (two workgroups per CU) unless the batch needs more than two workgroups

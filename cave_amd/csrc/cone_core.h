@@ -856,6 +856,83 @@ CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
 #include "cone_dense.h"
 namespace cave {
 
+// w.H = M W M^T as a symmetric band (H[j * ldh + t] = H(j + t, j)), W_kk = weight(k).  Accumulated in 64-bit FIXED
+// POINT (the zero bit pattern is shared with the doubles): integer adds are associative, so the sums -- and with them
+// the whole projection -- do not depend on the order in which lanes and waves arrive; two launches give the same bits
+// (the fp64 atomics spread results by 1e-7).  in_lds: the whole band fits the (idle) LDS ring window and is
+// accumulated there with LDS atomics, then copied out; otherwise straight into the workspace.
+template <class C, bool PM1, class W>
+CAVE_HD void band_hessian(C& c, const SolveView& v, SolveWork& w, bool in_lds, W&& weight) {
+  constexpr int NT = C::NT;
+  const int p = v.p, d = v.d, ldh = w.ldh;
+  auto accumulate = [&](auto Hacc, auto add) {
+    for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
+    c.sync();
+    // Four coordinates per thread at a time, their column extents and first two entries requested
+    // together: on the packed path the cone is read straight from the store (HBM / L2), and one
+    // dependent load per entry would cost a full memory latency each.
+    constexpr int G = 4;
+    for (int base = c.tid(); base < d; base += G * NT) {
+      uint32_t lo[G], hi[G], a0[G], a1[G];
+      double wk[G], x0[G], x1[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int k = base + u * NT;
+        const bool in = k < d;
+        const int kc = in ? k : d - 1;
+        lo[u] = v.cptr[kc];
+        hi[u] = in ? v.cptr[kc + 1] : lo[u];
+        wk[u] = in ? weight(kc) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;  // clamp: loads are unconditional
+        const uint32_t e0 = lo[u] < last ? lo[u] : last, e1 = lo[u] + 1u < last ? lo[u] + 1u : last;
+        csc_entry<PM1>(v, e0, a0[u], x0[u]);
+        csc_entry<PM1>(v, e1, a1[u], x1[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (!(wk[u] > 1e-14) || hi[u] == lo[u]) continue;
+        add(Hacc + a0[u] * ldh, wk[u] * x0[u] * x0[u]);
+        if (hi[u] - lo[u] >= 2u) {
+          add(Hacc + a1[u] * ldh, wk[u] * x1[u] * x1[u]);
+          add(Hacc + (a0[u] * ldh + (a1[u] - a0[u])), wk[u] * x1[u] * x0[u]);  // columns are sorted: a0 < a1
+        }
+        for (uint32_t e1 = lo[u] + 2u; e1 < hi[u]; ++e1) {  // columns with more than two entries (cut rows)
+          uint32_t a, b;
+          double v1, v2;
+          csc_entry<PM1>(v, e1, a, v1);
+          const double va = wk[u] * v1;
+          add(Hacc + a * ldh, va * v1);
+          for (uint32_t e2 = lo[u]; e2 < e1; ++e2) {
+            csc_entry<PM1>(v, e2, b, v2);
+            add(Hacc + (b * ldh + (a - b)), va * v2);
+          }
+        }
+      }
+    }
+  };
+  const double hsc = w.hscale, hiv = w.hinv;
+  if (in_lds) {
+    auto Hl = space_cast<3>(w.bwin);
+    accumulate(Hl, [&](decltype(Hl) q, double x) {
+      c.atomic_add_i64_lds(reinterpret_cast<typename SpacePtr<long long, 3>::type>(q), (long long)llrint(x * hsc));
+    });
+    c.sync();
+    auto Hq = reinterpret_cast<typename SpacePtr<long long, 3>::type>(Hl);
+    for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = (double)Hq[idx] * hiv;
+  } else {
+    accumulate(w.H, [&](double* q, double x) { c.atomic_add_i64(reinterpret_cast<long long*>(q), (long long)llrint(x * hsc)); });
+    c.sync();
+    long long* Hq = reinterpret_cast<long long*>(w.H);
+    for (int idx = c.tid(); idx < p * ldh; idx += NT) {
+      const long long qv = Hq[idx];
+      w.H[idx] = (double)qv * hiv;
+    }
+  }
+}
+
 // does the context carry the lite index structures (SoloCtx)?
 template <class C, class = void> struct ctx_lite : std::false_type {};
 template <class C> struct ctx_lite<C, std::void_t<decltype(C::LITE)>> : std::bool_constant<C::LITE> {};
@@ -1116,80 +1193,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       double mu = (it < 6) ? CAVE_BMU0 * ymax * sched01 : 0.0;
       mu = fmax(mu, CAVE_BMU_COEF * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
       auto weight = [&](int k) -> double { return band_weight(v.usign[k], r[k], mu); };
-      if (dense_on) dense_hessian<C, PM1>(c, v, r, mu, w.dn);  // whole matrix in LDS, fixed point (cone_dense.h)
+      if (dense_on) dense_hessian<C, PM1>(c, v, weight, w.dn);  // whole matrix in LDS, fixed point (cone_dense.h)
       else if (hgen_on) {  // no bound rows, one-wave elimination: it builds the rows it needs itself (cone_band.h)
         w.gen.mu = mu;
         w.gen.r = r;
       } else {
-      auto accumulate = [&](auto Hacc, auto add) {
-        for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
-        c.sync();
-        // Four coordinates per thread at a time, their column extents and first two entries requested
-        // together: on the packed path the cone is read straight from the store (HBM / L2), and one
-        // dependent load per entry would cost a full memory latency each.
-        constexpr int G = 4;
-        for (int base = c.tid(); base < d; base += G * NT) {
-          uint32_t lo[G], hi[G], a0[G], a1[G];
-          double wk[G], x0[G], x1[G];
-#pragma unroll
-          for (int u = 0; u < G; ++u) {
-            const int k = base + u * NT;
-            const bool in = k < d;
-            const int kc = in ? k : d - 1;
-            lo[u] = v.cptr[kc];
-            hi[u] = in ? v.cptr[kc + 1] : lo[u];
-            wk[u] = in ? weight(kc) : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < G; ++u) {
-            const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;  // clamp: loads are unconditional
-            const uint32_t e0 = lo[u] < last ? lo[u] : last, e1 = lo[u] + 1u < last ? lo[u] + 1u : last;
-            csc_entry<PM1>(v, e0, a0[u], x0[u]);
-            csc_entry<PM1>(v, e1, a1[u], x1[u]);
-          }
-#pragma unroll
-          for (int u = 0; u < G; ++u) {
-            if (!(wk[u] > 1e-14) || hi[u] == lo[u]) continue;
-            add(Hacc + a0[u] * ldh, wk[u] * x0[u] * x0[u]);
-            if (hi[u] - lo[u] >= 2u) {
-              add(Hacc + a1[u] * ldh, wk[u] * x1[u] * x1[u]);
-              add(Hacc + (a0[u] * ldh + (a1[u] - a0[u])), wk[u] * x1[u] * x0[u]);  // columns are sorted: a0 < a1
-            }
-            for (uint32_t e1 = lo[u] + 2u; e1 < hi[u]; ++e1) {  // columns with more than two entries (cut rows)
-              uint32_t a, b;
-              double v1, v2;
-              csc_entry<PM1>(v, e1, a, v1);
-              const double va = wk[u] * v1;
-              add(Hacc + a * ldh, va * v1);
-              for (uint32_t e2 = lo[u]; e2 < e1; ++e2) {
-                csc_entry<PM1>(v, e2, b, v2);
-                add(Hacc + (b * ldh + (a - b)), va * v2);
-              }
-            }
-          }
-        }
-      };
-      // accumulated in 64-bit FIXED POINT (the zero bit pattern is shared with the doubles): integer adds are
-      // associative, so the sums -- and with them the whole projection -- do not depend on the order in which lanes
-      // and waves arrive; two launches give the same bits (the fp64 atomics spread results by 1e-7)
-      const double hsc = w.hscale, hiv = w.hinv;
-      if (in_lds) {
-        auto Hl = space_cast<3>(w.bwin);
-        accumulate(Hl, [&](decltype(Hl) q, double x) {
-          c.atomic_add_i64_lds(reinterpret_cast<typename SpacePtr<long long, 3>::type>(q), (long long)llrint(x * hsc));
-        });
-        c.sync();
-        auto Hq = reinterpret_cast<typename SpacePtr<long long, 3>::type>(Hl);
-        for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = (double)Hq[idx] * hiv;
-      } else {
-        accumulate(w.H, [&](double* q, double x) { c.atomic_add_i64(reinterpret_cast<long long*>(q), (long long)llrint(x * hsc)); });
-        c.sync();
-        long long* Hq = reinterpret_cast<long long*>(w.H);
-        for (int idx = c.tid(); idx < p * ldh; idx += NT) {
-          const long long qv = Hq[idx];
-          w.H[idx] = (double)qv * hiv;
-        }
-      }
+      band_hessian<C, PM1>(c, v, w, in_lds, weight);
       }
     } else {
     // generalised Hessian H = M W M^T, kept incrementally: H += (w_k - w_k_old) m_k m_k^T for the coordinates
@@ -1519,14 +1528,21 @@ CAVE_NOINLINE void solve_cone_band_call(C& c, const SolveView& v, SolveWork& w, 
 // Rows of a +a / -a pair and coordinates with both unit rows carry two multipliers whose barrier has no
 // minimiser (only their difference enters); they are left free, as an interior-point code's regularisation would.
 // On return w.res holds rho (so proj = y - rho = A^T lam of the iterate) and f = 1/2 ||rho||^2.
-template <class C, bool PM1>
+// BAND = true (large-cone path, round 3): the same steps on the band / dense forms of the Newton system -- the
+// smoothed Hessian M diag(rho') M^T is accumulated by band_hessian (or dense_hessian: whole matrix in LDS), the barrier
+// terms z_i / theta_i go onto its diagonal, and one band LDL^T (solve_spd_band / solve_spd_band_wave, no fixed rows)
+// or one complete dense LDL^T gives the step; the weights rho' live in the search-direction scratch w.q (doubles).
+template <class C, bool PM1, bool BAND = false>
 CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, int steps) {
   const int NT = C::NT;
   const int p = v.p, d = v.d, ldh = w.ldh;
   double* theta = w.theta;
   double* r = w.res;
   double* rc = w.rc;
-  float* wgt = w.wold;
+  using WT = std::conditional_t<BAND, double, float>;
+  WT* wgt;
+  if constexpr (BAND) wgt = w.q;
+  else wgt = w.wold;
   SolveResult out;
   out.iters = 0;
   out.status = ST_OK;
@@ -1561,7 +1577,7 @@ CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, 
       else if (u == 2) { rho = 0.5 * (s + q); dr = 0.5 * (1.0 + s / q); }
       else if (u == 3) { rho = 0.0; dr = 0.0; }
       rc[k] = rho;
-      wgt[k] = (float)dr;
+      wgt[k] = (WT)dr;
       acc += rho * rho;
     }
     const double f = 0.5 * c.reduce_sum(acc);
@@ -1570,9 +1586,40 @@ CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, 
   };
   int it = 0;
   for (; it < steps && p > 0; ++it) {
-    gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+    gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
     smooth_residual(tau);
-    gradient<C, PM1>(c, v, rc, w.g);  // g = -M rho
+    gradient<C, PM1, BAND>(c, v, rc, w.g);  // g = -M rho
+    if constexpr (BAND) {
+      auto weight = [&](int k) -> double { return (double)wgt[k]; };
+      if (w.dn.on) dense_hessian<C, PM1>(c, v, weight, w.dn);
+      else band_hessian<C, PM1>(c, v, w, w.band_hot && p <= ldh, weight);
+      c.sync();
+      for (int i = c.tid(); i < p; i += NT) {
+        double rhs = -w.g[i];
+        if (!v.vkind[i]) {
+          const double inv = 1.0 / theta[i];
+          rhs += tau * inv;
+          if (w.dn.on) w.dn.A[fold_base(p, (int)w.dn.pos[i])] += z[i] * inv;
+          else w.H[i * ldh] += z[i] * inv;
+        }
+        if (w.dn.on) w.dn.z[w.dn.pos[i]] = rhs;
+        else w.g2[i] = rhs;
+      }
+      c.sync();
+      if (w.dn.on) {
+        dense_factor(c, w.dn, p, 1e-12, p);
+        dense_backsub(c, w.dn, p, p);
+        for (int i = c.tid(); i < p; i += NT) w.step[i] = w.dn.x[w.dn.pos[i]];
+      } else {
+#if defined(CAVE_GPU_CODE)
+        if (w.band_wave) solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, w.g2, w.act, p, 1e-12, w.bwin, w.bfac, w.bz, w.step, w.bstg, nullptr);
+        else
+#endif
+        if (w.band_hot) solve_spd_band<C, true>(c, w.H, w.bw, w.g2, w.act, p, 1e-12, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);
+        else solve_spd_band<C, false>(c, w.H, w.bw, w.g2, w.act, p, 1e-12, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);
+      }
+      c.sync();
+    } else {
     for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
     c.sync();
     for (int k = c.tid(); k < d; k += NT) {
@@ -1606,6 +1653,7 @@ CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, 
     c.sync();
     c.solve_spd(w.H, ldh, w.g2, w.act, p, 1e-12, w.step);
     c.sync();
+    }
     double ap = 1e300, ad = 1e300;
     for (int i = c.tid(); i < p; i += NT) {
       double dz = 0.0;
@@ -1633,7 +1681,7 @@ CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, 
     if (!(tau > tau_min)) tau = tau_min;
     c.sync();
   }
-  gather_mt<C, PM1>(c, v, w.y, theta, -1.0, r);
+  gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
   const double f = smooth_residual(tau);
   for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];
   c.sync();
@@ -1646,6 +1694,11 @@ CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, 
 template <class C>
 CAVE_HD SolveResult solve_cone_ipm(C& c, const SolveView& v, SolveWork& w, int steps) {
   return v.pm1 ? solve_cone_ipm_impl<C, true>(c, v, w, steps) : solve_cone_ipm_impl<C, false>(c, v, w, steps);
+}
+// large-cone path (a real call, like solve_cone_band_call)
+template <class C>
+CAVE_NOINLINE void solve_cone_ipm_band_call(C& c, const SolveView& v, SolveWork& w, int steps, SolveResult* out) {
+  *out = v.pm1 ? solve_cone_ipm_impl<C, true, true>(c, v, w, steps) : solve_cone_ipm_impl<C, false, true>(c, v, w, steps);
 }
 
 // half bandwidth of M M^T in the reduced-row order: the widest span of reduced rows meeting in one

@@ -81,8 +81,8 @@ CAVE_HD void dense_order(C& c, const SolveView& v, DenseWork& dw, uint32_t* tmp)
 // A = M W M^T (folded upper triangle, elimination order), accumulated in fixed point.
 // (The pieces below are REAL calls, like the band solvers: inlined into the Newton iteration they inherit -- and add
 //  to -- a register file that already spills; as functions each gets its own allocation.)
-template <class C, bool PM1>
-CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, const double* r, double mu, const DenseWork& dw) {
+template <class C, bool PM1, class W>
+CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const DenseWork& dw) {
   constexpr int NT = C::NT;
   const int p = v.p, d = v.d;
   const int ne = (int)fold_entries(p);
@@ -114,7 +114,7 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, const double* r, doub
       const int kc = in ? k : d - 1;
       lo[u] = v.cptr[kc];
       cnt[u] = in ? v.cptr[kc + 1] - lo[u] : 0u;
-      wk[u] = in ? band_weight(v.usign[kc], r[kc], mu) : 0.0;
+      wk[u] = in ? weight(kc) : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < G; ++u)
@@ -165,9 +165,9 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, const double* r, doub
 // after one barrier every lane takes the same TWO COLUMNS of every trailing row, so the eight pivot-row operands are
 // read once per step and a trailing row costs four broadcast reads, one read and one write of the target pair.
 template <class C>
-CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel) {
+CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel, int npiv = -1) {
   constexpr int NT = C::NT, NB = kDenseNB;
-  const int nF = dw.nF;
+  const int nF = npiv >= 0 ? npiv : dw.nF;  // (npiv = p: complete factorisation, interior-point steps)
   auto A = space_cast<3>(dw.A);
   auto z = space_cast<3>(dw.z);
   auto dinv = space_cast<3>(dw.dinv);
@@ -315,8 +315,8 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
 
 // x[q], q < nF, from the factor of the first block, the eliminated right-hand side and the given x[nF ..]
 template <class C>
-CAVE_NOINLINE void dense_backsub(C& c, const DenseWork& dw, int p) {
-  const int nF = dw.nF;
+CAVE_NOINLINE void dense_backsub(C& c, const DenseWork& dw, int p, int npiv = -1) {
+  const int nF = npiv >= 0 ? npiv : dw.nF;
   auto A = space_cast<3>(dw.A);
   auto z = space_cast<3>(dw.z);
   auto x = space_cast<3>(dw.x);

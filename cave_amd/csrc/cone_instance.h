@@ -347,8 +347,15 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     c.sync();
     SolveResult r;
     bool lite = false;
-    if constexpr (LARGE) { if (mode == MODE_IPM) return ST_BAD_INPUT; }  // rejected by the host entry points
-    else if (mode == MODE_IPM) {
+    if constexpr (LARGE) {
+      if (mode == MODE_IPM) {  // interior-point inner mode on the band / dense forms (round 3)
+        w.gen.on = false;  // the band is materialised: its weights are the smoothed clip's, not band_weight's
+        for (int i = c.tid(); i < p; i += C::NT) w.act[i] = 0;
+        c.sync();
+        solve_cone_ipm_band_call(c, vv, w, max_iter, &r);
+        lite = true;  // (handled)
+      }
+    } else if (mode == MODE_IPM) {
       r = solve_cone_ipm(c, vv, w, max_iter);
       lite = true;  // (handled)
     }

@@ -285,9 +285,6 @@ class ConeStore:
             out["status"], out["iters"] = status, iters
             if B == 0:
                 return out
-            if self.large and int(mode) == _lib.MODE_INNER_IPM:
-                raise NotImplementedError("solver_kwargs={'inner': 'ipm'} is implemented on the LDS-resident path only "
-                                          "(reduced systems up to 64 rows); these cones run on the large-cone path")
             if self.large:
                 slice_bytes = int(lib.cave_hip_packed_large_slice_bytes(d, self.max_rows, self.band_entries))
                 slots = _lib.large_slots(dev, B, slice_bytes)

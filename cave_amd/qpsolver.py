@@ -359,9 +359,6 @@ def cone_op_dense(tight_ctrs: torch.Tensor, pred_cost: torch.Tensor | None, mode
             _lib.check(rc, "cave_hip_cone_dense_large")
 
         def run_large() -> None:
-            if int(mode) == _lib.MODE_INNER_IPM:
-                raise NotImplementedError("solver_kwargs={'inner': 'ipm'} is implemented on the LDS-resident path "
-                                          "only (reduced systems up to 64 rows); these cones need the large-cone path")
             cap, band = _large_hint.get((m, d), _large_guess(m, d))
             cap = max(cap, nnz_cap)
             for attempt in range(5):

@@ -6,6 +6,7 @@ BASELINE configs[0] sizes (5x5 grid, 100 instances, batch 32); `--problem tsp` i
 
     python examples/train_sp_cave.py [--grid 5 5] [--num-data 100] [--batch 32] [--epochs 10] [--packed]
     python examples/train_sp_cave.py --problem tsp --nodes 10 --packed --warm-start
+    python examples/train_sp_cave.py --grid 30 30 --num-data 64 --batch 32 --epochs 3 --packed --inner ipm
 """
 
 import argparse
@@ -32,6 +33,10 @@ def main(argv=None):
     ap.add_argument("--packed", action="store_true", help="device-resident packed cones instead of dense padding")
     ap.add_argument("--problem", default="sp", choices=["sp", "tsp"])
     ap.add_argument("--nodes", type=int, default=10, help="TSP size (Held-Karp: <= 14)")
+    ap.add_argument("--inner", default="push", choices=["push", "ipm"],
+                    help="CaVE+ interior point: 'push' (nnls-style: exact projection pushed towards the average normal) or "
+                         "'ipm' (truncated interior-point iterate, as the reference's Clarabel max_iter=3: src/cave.py:213-214)")
+    ap.add_argument("--max-iter", type=int, default=3, help="interior-point steps of --inner ipm")
     ap.add_argument("--warm-start", action="store_true",
                     help="(with --packed) start each projection from the multipliers of the previous epoch")
     args = ap.parse_args(argv)
@@ -57,7 +62,8 @@ def main(argv=None):
     if args.variant == "exact":
         cave = exactConeAlignedCosine(_Model(), solver="hip")
     elif args.variant == "inner":
-        cave = innerConeAlignedCosine(_Model(), solver="hip", seed=0)
+        cave = innerConeAlignedCosine(_Model(), solver="hip", seed=0, max_iter=args.max_iter,
+                                      solver_kwargs={"inner": args.inner} if args.inner != "push" else None)
     else:
         cave = innerConeAlignedCosine(_Model(), solver="hip", solve_ratio=0.3, inner_ratio=0.2, seed=0)
 

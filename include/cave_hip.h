@@ -63,7 +63,8 @@ extern "C" {
  * tau shrinking every step; the multipliers of the signed-unit rows are eliminated in closed form, which turns
  * their clip into its Chen-Harker-Kanzow-Smale smoothing.  Every multiplier of the iterate is > 0; proj / rnorm
  * are those of the iterate and tend to the exact projection as max_iter grows.  An emulation: Clarabel's own
- * iterates are not reproduced (no Clarabel in the image: parity unpinned).  Fast path only (not *_large). */
+ * iterates are not reproduced (no Clarabel in the image: parity unpinned).  Since v8 also on the large-cone path
+ * (cave_hip_cone_dense_large / cave_hip_cone_packed_large): one band or dense LDL^T per interior-point step. */
 #define CAVE_MODE_INNER_IPM 5
 
 int32_t cave_hip_version(void);

@@ -120,7 +120,7 @@ int32_t cave_emul_cone_dense_large(const float* ctrs, const float* pred, int64_t
   if (nnz_cap <= 0 || lds_bytes <= 0 || slice_bytes <= 0 || slice_bytes >= ((int64_t)1 << 32)) return CAVE_E_INVALID;
   DenseParams P;
   P.ctrs = ctrs; P.pred = pred; P.B = B; P.m = (int32_t)m_max; P.d = (int32_t)d; P.mode = mode;
-  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100;
+  P.sign = sign; P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100);
   P.nnz_cap = (uint32_t)nnz_cap; P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   std::vector<unsigned char> smem((size_t)lds_bytes), ws((size_t)slice_bytes);
@@ -153,7 +153,7 @@ int32_t cave_emul_cone_packed_large(const cave_cone_store* store, const int64_t*
   if (!store || lds_bytes <= 0 || slice_bytes <= 0 || slice_bytes >= ((int64_t)1 << 32)) return CAVE_E_INVALID;
   PackedParams P;
   P.store = *store; P.ids = ids; P.pred = pred; P.B = B; P.mode = mode; P.sign = sign;
-  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : 100; P.lds_bytes = (uint32_t)lds_bytes;
+  P.inner_ratio = inner_ratio; P.max_iter = max_iter > 0 ? max_iter : (mode == CAVE_MODE_INNER_IPM ? 3 : 100); P.lds_bytes = (uint32_t)lds_bytes;
   P.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   std::vector<unsigned char> smem((size_t)lds_bytes), ws((size_t)slice_bytes);
   SerialCtx c;

@@ -55,6 +55,88 @@ def test_ipm_serial_kernel_code(golden):
     check_ipm_properties(lambda c, y, k: E.cone_dense(c, y, MODE_IPM, sign=-1.0, max_iter=k), golden)
 
 
+def _large_cases():
+    from cave_amd import synth
+
+    c1, y1, _ = synth.sp_batch(12, 12, 2, seed=5)     # narrow band, 144 free rows
+    c2, y2, _ = synth.tsp_batch(30, 2, seed=5)        # ~33 rows, the cut rows carry bounds (barrier terms)
+    return {"sp12": (c1, y1), "tsp30": (c2, y2)}
+
+
+def check_ipm_large(run):
+    """The interior-point inner mode on the large-cone path: strictly interior by LP at the
+    reference's max_iter = 3, convergence to the nnls projection at 40 steps (<= 4e-6), finite loss and gradient."""
+    for name, (ctrs, costs) in _large_cases().items():
+        po, _ = O.batch_project(-costs, ctrs)
+        sc = float(np.abs(costs).max())
+        errs = {}
+        for steps in (3, 12, 40):
+            o = run(ctrs, costs, steps)
+            assert (o["status"] == 0).all() and np.isfinite(o["loss"]).all() and np.isfinite(o["grad"]).all(), (name, steps)
+            errs[steps] = float(np.abs(o["proj"] - po).max() / sc)
+            if steps == 3:
+                assert interior_margin(ctrs[0], o["proj"][0].astype(np.float64), 1e-6 * sc) <= 1e-5 * sc, name
+                assert (o["iters"] == 3).all()
+        assert errs[40] <= 4e-6 and errs[40] <= errs[3], (name, errs)
+
+
+def test_ipm_large_path_serial_kernel_code(golden):
+    """Same properties through the large-cone code (band LDL^T / dense LDL^T per interior-point step), serial build:
+    the small fixture cones forced onto that path, a 12x12 grid (band) and TSP-30 cones (bound rows)."""
+    E = Emul()
+    check_ipm_properties(lambda c, y, k: E.cone_dense_large(c, y, MODE_IPM, sign=-1.0, max_iter=k), golden)
+    check_ipm_large(lambda c, y, k: E.cone_dense_large(c, y, MODE_IPM, sign=-1.0, max_iter=k))
+
+
+@pytest.mark.gpu
+def test_ipm_on_the_large_cone_path_gpu():
+    """GPU: interior-point inner mode through cave_hip_cone_packed_large at 4 / 2 / 1 waves (one-wave band elimination,
+    dense LDL^T), and the module on a packed store of 30x30 grids (BASELINE configs[4] names CaVE+)."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.cave import EPO, innerConeAlignedCosine
+    from cave_amd.dataset import ConeStore, PackedBatch
+
+    ALL = ("proj", "rnorm", "target", "loss", "grad")
+    stores = {}
+    for waves in (4, 2, 1):
+        def run(c, y, k):
+            key = c.shape
+            if key not in stores:
+                stores[key] = ConeStore.from_dense(torch.tensor(c, device="cuda"), chunk=2)
+            st = stores[key]
+            st.large, st.large_waves = True, waves
+            if not st.band_entries:
+                st.band_entries, st.max_bw = st._max_band_entries()
+                st.large_lds = 64 * 1024
+            o = st.cone_op(torch.arange(len(c), device="cuda"), torch.tensor(y, device="cuda"), MODE_IPM, -1.0, 0.0,
+                           max_iter=k, outputs=ALL)
+            return {kk: v.cpu().numpy() for kk, v in o.items()}
+        check_ipm_large(run)
+
+    class M:
+        modelSense = EPO.MINIMIZE
+
+    c, y, _ = synth.sp_batch(30, 30, 2, seed=3)
+    store = ConeStore.from_dense(torch.tensor(c, device="cuda"), chunk=2)
+    assert store.large
+    batch = PackedBatch(store, torch.arange(2, device="cuda"))
+    pred = torch.tensor(y, device="cuda")
+    losses = {}
+    for k in (3, 40):
+        mod = innerConeAlignedCosine(M(), solver="hip", solver_kwargs={"inner": "ipm"}, max_iter=k, reduction="none")
+        p = pred.clone().requires_grad_(True)
+        l = mod(p, batch)
+        l.sum().backward()
+        assert torch.isfinite(l).all() and torch.isfinite(p.grad).all()
+        losses[k] = l.detach()
+    from cave_amd.cave import exactConeAlignedCosine
+
+    exact = exactConeAlignedCosine(M(), solver="hip", reduction="none")(pred, batch)
+    assert float((losses[40] - exact).abs().max()) <= 1e-5 and float((losses[3] - exact).abs().max()) > 1e-6
+
+
 @pytest.mark.gpu
 def test_ipm_hip_kernels_and_module(golden):
     import torch
