@@ -31,7 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+LARGE_PMC = {"tsp100": os.path.join("profiles", "r03_large_tsp100_pmc_summary.json"),
+             "sp30": os.path.join("profiles", "r03_large_sp30_pmc_summary.json")}
 
 
 def parse(argv=None):
@@ -50,9 +52,11 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip packed-path / train-step side measurements")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the side measurements at the instance sizes of BASELINE configs 3-5")
+    ap.add_argument("--no-large-cpu", action="store_true",
+                    help="skip the one-instance CPU timing of the 30x30 grid in other_configs (about a minute of host time)")
     ap.add_argument("--pipeline", action="store_true",
                     help="overlap the pack stage of step i+1 (side stream) with the solve stage of step i "
-                         "(measured: 182 vs 192 us/step -- the two kernels slow each other down; off by default)")
+                         "(measured r03: 206 vs 176 us/step -- the two kernels slow each other down; off by default)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at --gpus 1 (world size 1) and run the per-step "
                          "[sum loss, count] all-reduce and the sharded-store leg: the code path of an N-GPU run")
@@ -367,15 +371,15 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernels, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
                          "kernel_ms_note": "HIP events around one operator call = every kernel of the step (the split "
-                                           "form launches two); per-kernel durations: profiles/r02_kernel_stats.csv",
+                                           "form launches two); per-kernel durations: profiles/r03_kernel_stats.csv",
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
             "pipeline": {"across_steps": bool(args.pipeline and split),
                          "unpipelined_ms_per_step": kern_ms,
                          "note": "--pipeline overlaps the pack stage of step i+1 with the solve stage of step i on a side "
-                                 "stream (cave_amd.qpsolver.prepare_dense); measured gain ~5 %: co-resident, the two "
-                                 "kernels slow each other down (solve 130 -> 175 us, pack 60 -> 147 us)."},
+                                 "stream (cave_amd.qpsolver.prepare_dense); measured r03: SLOWER (206 vs 176 us per step): "
+                                 "co-resident, the two kernels slow each other down; off by default."},
         }
         if use_dist:
             res["process_group"] = {"backend": "nccl (RCCL)", "world_size": world,
@@ -385,7 +389,7 @@ def main(argv=None):
         if not args.no_extras and world == 1:
             res.update(extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs))
             if not args.no_other_configs:
-                res["other_configs"] = other_configs(dev)
+                res["other_configs"] = other_configs(dev, not args.no_large_cpu)
         if args.cpu_sample > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(ctrs_np[ids], -pred_np, args.cpu_sample, f"TSP-{args.tsp}")
             res["gpu_over_cpu_1core_nnls"] = res["value"] / res["cpu_baseline"]["value"]
@@ -582,7 +586,7 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
     return out
 
 
-def other_configs(dev):
+def other_configs(dev, large_cpu=True):
     """Side measurements (not `value`): one GPU's share of BASELINE configs 3-5 on the packed store, every
     batch slot a DISTINCT synthetic cone (generated in coordinate form, densified on the GPU a chunk at a
     time and packed), each with its own roofline and a sub-sampled CPU figure."""
@@ -592,7 +596,7 @@ def other_configs(dev):
     from cave_amd import _lib, synth
     from cave_amd.dataset import ConeStore
 
-    def run(name, kind, size, B, mode, chunk, cpu_n, cpu_note):
+    def run(name, kind, size, B, mode, chunk, cpu_n, cpu_note, tag=None, cpu_recorded=None):
         items, costs, _ = synth.coo_batch(kind, size, B, seed=0)
         d = int(costs.shape[1])
         m_max = max(it[3] for it in items)
@@ -625,6 +629,26 @@ def other_configs(dev):
                             "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                             "kernel": "cone_packed_large_kernel" if store.large else "cone_packed_kernel",
                             "kernel_ms": k_ms, "algorithmic_bytes": alg, "format": "packed store"}}
+        if tag in LARGE_PMC:  # HBM bytes per launch of this very workload, from separate rocprofv3 --pmc passes
+            try:
+                pm = json.load(open(os.path.join(ROOT, LARGE_PMC[tag])))
+                res["roofline"]["traffic"] = pm.get("hbm_bytes_per_launch")
+                res["roofline"]["traffic_source"] = LARGE_PMC[tag] + " (tools/diag/pmc_run_large.sh, same batch)"
+                res["roofline"]["traffic_over_algorithmic"] = pm.get("hbm_bytes_per_launch") / alg
+            except Exception:  # noqa: BLE001
+                pass
+        if store.large and B > 256:
+            # the slowest instance beside the mean: 256 instances = one workgroup per compute unit, so the launch
+            # time is the latency of its slowest instance; mean = whole-batch time x resident workgroups / batch
+            sub = ids[:256]
+            kv = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+            for a, b in kv:
+                a.record()
+                store.cone_op(sub, pred[:256], mode, -1.0, 0.2, check=False, outputs=outs)
+                b.record()
+            torch.cuda.synchronize()
+            res["slowest_instance_ms_alone_on_its_cu"] = float(np.min([a.elapsed_time(b) for a, b in kv[1:]]))
+            res["newton_iters_max_of_those_256"] = int(o["iters"][:256].max())
         if store.large:
             # the training situation (cones static per instance, predictions drifting from step to step): per-instance
             # multiplier cache on, three steps of drift to fill it, then timed steps that keep drifting
@@ -659,26 +683,33 @@ def other_configs(dev):
             dtc = time.perf_counter() - t0
             res["cpu_baseline"] = {"value": cpu_n / dtc, "unit": "projections/s", "cores": 1, "kind": "port",
                                    "sample": f"{cpu_n} instance(s) of this batch, serial, {dtc:.1f} s"}
+        elif cpu_recorded is not None:
+            res["cpu_baseline"] = dict(cpu_recorded)
         else:
             res["cpu_baseline"] = {"value": None, "unit": "projections/s", "cores": 1, "kind": "port", "sample": cpu_note}
         return res
 
     out = []
     specs = [
-        ("configs[2] TSP-50, CaVE Exact, 4096/8 GPUs", "tsp", 50, 512, _lib.MODE_EXACT, 32, 2, ""),
-        ("configs[3] TSP-100, QP branch of CaVE Hybrid (inner_ratio 0.2), 2048/4 GPUs", "tsp", 100, 512,
-         _lib.MODE_INNER, 4, 0,
-         "not timed in the default run: one TSP-100 instance takes ~26 min in scipy.optimize.nnls "
-         "(measured when tests/golden/large.npz was generated)"),
-        ("configs[4] shortest path 30x30, CaVE+ (inner), 8192/8 GPUs", "sp", (30, 30), 1024, _lib.MODE_INNER, 32, 0,
-         "not timed in the default run: one 30x30 instance takes ~44 s in scipy.optimize.nnls "
-         "(measured when tests/golden/large.npz was generated)"),
+        dict(name="configs[2] TSP-50, CaVE Exact, 4096/8 GPUs", kind="tsp", size=50, B=512, mode=_lib.MODE_EXACT, chunk=32,
+             cpu_n=2, cpu_note=""),
+        # one TSP-100 projection takes scipy.optimize.nnls 26 minutes: recorded once (with the fixture), not re-timed per run
+        dict(name="configs[3] TSP-100, QP branch of CaVE Hybrid (inner_ratio 0.2), 2048/4 GPUs", kind="tsp", size=100, B=512,
+             mode=_lib.MODE_INNER, chunk=4, cpu_n=0, cpu_note="", tag="tsp100",
+             cpu_recorded={"value": 1.0 / (26 * 60), "unit": "projections/s", "cores": 1, "kind": "reference",
+                           "sample": "RECORDED, not timed in this run: scipy.optimize.nnls (the reference's solver, "
+                                     "src/cave.py:307) on 1 TSP-100 instance took 26 min when tests/golden/large.npz was "
+                                     "generated (tests/golden/make_golden_large.py, this image's 8-core container)"}),
+        # one 30x30 projection through the CPU port: ~45-75 s (SciPy: 44 s when the fixture was generated)
+        dict(name="configs[4] shortest path 30x30, CaVE+ (inner), 8192/8 GPUs", kind="sp", size=(30, 30), B=1024,
+             mode=_lib.MODE_INNER, chunk=32, cpu_n=1 if large_cpu else 0, tag="sp30",
+             cpu_note="skipped (--no-large-cpu): one 30x30 instance takes the CPU port about a minute"),
     ]
     for spec in specs:
         try:
-            out.append(run(*spec))
+            out.append(run(**spec))
         except Exception as e:  # noqa: BLE001 - side measurement only
-            out.append({"workload": spec[0], "error": repr(e)[:300]})
+            out.append({"workload": spec["name"], "error": repr(e)[:300]})
     return out
 
 

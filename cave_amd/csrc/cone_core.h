@@ -1092,6 +1092,22 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   ymax = c.reduce_max(ymax);
   c.sync();
   double f = refresh_clipped(c, v, r, rc);
+  // Rounding floor of the gradient test: g_i = -sum_k m_ik rc_k is a sum of terms of size up to |m_ik| max|y|, so a
+  // projected gradient below a few ulps of (largest row 1-norm) * max|y| is zero to working precision.  Without it a
+  // start that is already optimal to the float32 resolution of y (y in the polar of the cone: g0n ~ 6e-8) asked for
+  // pgn <= 1e-11 * g0n, which no iterate can deliver -- flagged NOT_CONVERGED with the right projection in hand
+  // (found by tools/fuzz/fuzz_gpu.py seed 701, round 3: 1 of ~270 k adversarial instances).
+  double rmax1 = 0.0;
+  for (int i = c.tid(); i < p; i += NT) {
+    double s1 = (double)(v.mptr[i + 1] - v.mptr[i]);
+    if constexpr (!PM1) {
+      s1 = 0.0;
+      for (uint32_t e = v.mptr[i]; e < v.mptr[i + 1]; ++e) s1 += fabs((double)v.mval[e]);
+    }
+    rmax1 = fmax(rmax1, s1);
+  }
+  rmax1 = c.reduce_max(rmax1);
+  const double gfloor = 8.0 * 2.220446049250313e-16 * rmax1 * ymax;
   double g0n = 0.0;
   if (warm && p > 0) {
     // the convergence test is relative to the projected gradient AT theta = 0 (what a cold start measures in its
@@ -1175,7 +1191,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     // degenerate multipliers otherwise creep towards f = 0 at a linear rate.  The floor is absolute only for
     // |y| >= 1: a prediction of tiny norm (|y| < 4.5e-8 has f <= 1e-15 at theta = 0) must still be projected,
     // because the cosine target only sees the direction of proj.
-    if (!(pgn > tol_it * g0n) || f <= 1e-30 * yy || f <= 1e-15 * fmin(1.0, yy)) { converged = true; break; }
+    if (!(pgn > tol_it * g0n) || pgn <= gfloor || f <= 1e-30 * yy || f <= 1e-15 * fmin(1.0, yy)) { converged = true; break; }
     if constexpr (BAND) {
       // SMOOTHED generalised Hessian H = M W M^T.  W_kk in [0,1] is the derivative of
       // the CHKS smoothing of the one-sided clip at scale mu (1/2 at the kink, -> the 0/1 activity D_kk
@@ -1360,7 +1376,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       moved = c.reduce_max(mv) > 0.0;
     }
     CAVE_ACC(4);
-    if (!moved) { converged = !(pgn > 1e-6 * g0n); break; }
+    if (!moved) { converged = !(pgn > 1e-6 * g0n) || pgn <= gfloor; break; }
     // ---- exact line search on the true f along dv = tc - theta
     double psi0 = 0.0, amax = 1e300;
     for (int i = c.tid(); i < p; i += NT) {
@@ -1380,7 +1396,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     if (amax < 1.0) amax = 1.0;
     c.sync();
     CAVE_ACCF(21);
-    if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n); break; }
+    if (!(psi0 < 0.0)) { converged = !(pgn > 1e-6 * g0n) || pgn <= gfloor; break; }
     // q = M^T dv, so r(alpha) = r - alpha q.  When the cost dimension fits KREG coordinates per
     // thread, q and r stay in registers for the whole search and the residual update is fused in.
     double alpha, fn;
@@ -1476,7 +1492,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // shift a Hessian of condition 1e12+ gives a direction made of round-off, and "no gain along it"
       // says nothing about optimality.)
       if (reg_rel >= 1e-6 && !(pgn > 1e-8 * g0n)) { converged = true; ++it; break; }
-      if (reg_rel >= 1e-2) { converged = !(pgn > 1e-8 * g0n); ++it; break; }
+      if (reg_rel >= 1e-2) { converged = !(pgn > 1e-8 * g0n) || pgn <= gfloor; ++it; break; }
       reg_rel *= 1e3;
     } else if (reg_rel > 1e-12) reg_rel *= 0.1;
   }

@@ -346,7 +346,11 @@ template <class P, class T> static inline T __hip_atomic_fetch_add(P p, T v, int
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) ::simt::update_dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_mbcnt_lo(m, b) ::simt::mbcnt_lo((uint32_t)(m), (uint32_t)(b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) ::simt::mbcnt_hi((uint32_t)(m), (uint32_t)(b))
+#ifdef SIMT_APPROX_RCP
+#define __builtin_amdgcn_rcp(x) ((double)(1.0f / (float)(x)))  /* ~24 bits, like v_rcp_f64 before its Newton steps */
+#else
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
+#endif
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)

@@ -7,7 +7,11 @@ Inputs (fixture data, kept in the .npz itself so this script can be re-run):
             before the zig-zag extrapolation and the residual floor (cone_core.h) -- degenerate cones with
             duplicated rows and the prediction inside the cone;
   * t1..t4  tiny-norm predictions (|y| from 1e-6 down to 1e-12) on a generic cone: a residual floor that is
-            absolute in |y| would declare these converged at theta = 0.
+            absolute in |y| would declare these converged at theta = 0;
+  * p1      (round 3, tools/fuzz/fuzz_gpu.py seed 701) the NEGATIVE of a point of the cone: theta = 0 is optimal
+            to the float32 resolution of y, the initial projected gradient is ~6e-8 and a convergence test relative
+            to it alone can never be met -- the solver returned the right projection flagged NOT_CONVERGED until
+            the gradient test got its rounding floor (cone_core.h, gfloor).
 Run from the repo root (needs /root/reference and scipy; NOT run on the GPU box):
     python tests/golden/make_regress.py
 """
@@ -46,6 +50,9 @@ def main():
         y0 = rng.standard_normal(7).astype(np.float32)
         for j, s in enumerate((1e-6, 3e-8, 1e-9, 1e-12), 1):
             cases[f"t{j}_A"], cases[f"t{j}_y"] = A, (y0 * np.float32(s)).astype(np.float32)
+    if "p1_A" not in cases:  # added in round 3 (the prediction enters with the sign the kernel saw: sign * pred = -y)
+        z = np.load(os.path.join(ROOT, "tools", "diag", "noconv_r03.npz"))
+        cases["p1_A"], cases["p1_y"] = z["A"], (-z["y"]).astype(np.float32)
     out = dict(cases)
     for k in sorted(cases):
         if not k.endswith("_A"):
