@@ -34,6 +34,12 @@
 //   CAVE_WAVE_ORDER()   lanes of ONE wave exchange data through LDS across this point
 //   CAVE_LDS_WAIT()     the same, plus the wave's own LDS operations have completed (one-wave workgroups)
 //   CAVE_LDS_BARRIER()  workgroup barrier that waits for LDS traffic only (global loads stay in flight)
+// streamed once-read data (the dense cones): non-temporal loads leave the caches to the data that is re-read
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL) && !defined(CAVE_NO_NT_LOADS)
+#define CAVE_NT_LOAD_F4(p) ::cave::nt_load_f4(p)
+#else
+#define CAVE_NT_LOAD_F4(p) (*(p))
+#endif
 #if defined(CAVE_SIMT_EMUL)
 #define CAVE_WAVE_ORDER() ::simt::wave_sync()
 #define CAVE_LDS_WAIT() ::simt::wave_sync()

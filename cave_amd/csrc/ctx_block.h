@@ -247,7 +247,7 @@ struct BlockCtx {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint32_t i = r0 + woff + (uint32_t)u * 64u;
-        buf[u] = A4[i < n4 ? i : n4 - 1u];  // unconditional dwordx4 from a clamped index
+        buf[u] = CAVE_NT_LOAD_F4(&A4[i < n4 ? i : n4 - 1u]);  // unconditional dwordx4 from a clamped index; read once: nt
       }
     };
     auto scan_batch = [&](const float4* buf, uint32_t r0) {

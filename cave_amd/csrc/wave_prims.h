@@ -7,6 +7,15 @@
 
 namespace cave {
 
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+// 16-byte non-temporal load (global_load_dwordx4 ... nt): streamed once-read data stays out of the way of re-read data
+__device__ __forceinline__ float4 nt_load_f4(const float4* p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+#endif
+
 __device__ __forceinline__ double readlane_f64(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_readlane(lo, l);
