@@ -462,14 +462,21 @@ CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double*
   CAVE_ACC(12);
 }
 
-// smoothed weight of coordinate k (see solve_cone_impl): derivative of the CHKS smoothing of the one-sided clip
-CAVE_HD double band_weight(uint8_t u, double rk, double mu) {
+// smoothed weight of coordinate k (see solve_cone_impl): derivative of the CHKS smoothing of the one-sided clip,
+// 1/2 (1 + z / sqrt(1 + z^2)) with z = t / mu.  Takes 1 / mu (0: the binary weight) and a reciprocal square root: the
+// weight is evaluated once per coordinate and iteration (TSP-100: 4950 of them; four per band row in band_gen_rows),
+// and sqrt + two divisions were a quarter of the Hessian phase's instructions.
+CAVE_HD double band_weight(uint8_t u, double rk, double inv_mu) {
   if (u == 0) return 1.0;
   if (u == 3) return 0.0;
   const double t = (u == 2) ? rk : -rk;  // > 0 on the side that carries residual
-  if (mu > 0.0) {
-    const double zz = t / mu;
+  if (inv_mu > 0.0) {
+    const double zz = t * inv_mu;
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+    return 0.5 * (1.0 + zz * rsqrt(1.0 + zz * zz));
+#else
     return 0.5 * (1.0 + zz / sqrt(1.0 + zz * zz));
+#endif
   }
   return (t > 0.0) ? 1.0 : 0.0;
 }
@@ -564,7 +571,7 @@ CAVE_NOINLINE __device__ void band_gen_rows(const BandGen* gen_v, const int lane
   auto g_cvalc = space_cast<1>(uniform_ptr(gen->cvalc));
   auto g_usign = space_cast<1>(uniform_ptr(gen->usign));
   const double* g_r = uniform_ptr(gen->r);
-  const double g_mu = gen->mu;
+  const double g_mu = gen->mu;  // (1 / mu, see BandGen)
   const bool g_pm1 = gen->mval == nullptr;
   if (lane >= n) return;
   constexpr int EB = 4, CB = 3;

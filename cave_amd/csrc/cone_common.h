@@ -180,7 +180,7 @@ struct BandGen {
   const float* cvalc;
   const uint8_t* usign;
   const double* r;        // unclipped residual of the current iterate
-  double mu;              // smoothing scale of this iteration
+  double mu;              // 1 / (smoothing scale of this iteration), 0: binary weights
   double hdiag;           // bound on the diagonal of H (largest squared row norm): scale of the Levenberg shift
 };
 

@@ -1208,10 +1208,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       const bool in_lds = w.band_hot && p <= ldh;
       double mu = (it < 6) ? CAVE_BMU0 * ymax * sched01 : 0.0;
       mu = fmax(mu, CAVE_BMU_COEF * ymax * fmin(pgn / g0n, cap07));  // capped: see the fast path below
-      auto weight = [&](int k) -> double { return band_weight(v.usign[k], r[k], mu); };
+      const double inv_mu = mu > 0.0 ? 1.0 / mu : 0.0;
+      auto weight = [&](int k) -> double { return band_weight(v.usign[k], r[k], inv_mu); };
       if (dense_on) dense_hessian<C, PM1>(c, v, weight, w.dn);  // whole matrix in LDS, fixed point (cone_dense.h)
       else if (hgen_on) {  // no bound rows, one-wave elimination: it builds the rows it needs itself (cone_band.h)
-        w.gen.mu = mu;
+        w.gen.mu = inv_mu;
         w.gen.r = r;
       } else {
       band_hessian<C, PM1>(c, v, w, in_lds, weight);
