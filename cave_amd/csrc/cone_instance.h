@@ -572,27 +572,69 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
     float* cvalc = pm1 ? nullptr : ar.get<float>(nz > 0 ? nz : 1);
     if (ar.ovf) st = ST_TOO_LARGE;
     else {
-      for (int k = c.tid(); k < d; k += NT) {
-        y[k] = P.pred ? P.sign * P.pred[b * d + k] : 0.f;
-        usign[k] = S.usign[slot * d + k];
-        if (need_avg) avg[k] = S.avg[slot * d + k];
+      // The instance comes from global memory (HBM / L2: ~1 k cycles per dependent load): every loop below requests
+      // U rounds of operands before it stores any, so a 530-entry TSP-20 cone costs three memory round trips instead
+      // of nine (measured: the load was 15 k of the one-wave kernel's 32 k cycles outside the Newton loop).
+      constexpr int U = 4;
+      for (int k0 = c.tid(); k0 < d; k0 += U * NT) {
+        float yv[U], av[U];
+        uint8_t uv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = k0 + u * NT, kc = k < d ? k : d - 1;
+          yv[u] = P.pred ? P.pred[b * d + kc] : 0.f;
+          uv[u] = S.usign[slot * d + kc];
+          av[u] = need_avg ? S.avg[slot * d + kc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = k0 + u * NT;
+          if (k < d) {
+            y[k] = P.sign * yv[u];
+            usign[k] = uv[u];
+            if (need_avg) avg[k] = av[u];
+          }
+        }
       }
       if (need_proj) {
-        for (int k = c.tid(); k <= d; k += NT) cptr[k] = S.cptr[slot * (d + 1) + k];
+        for (int k0 = c.tid(); k0 <= d; k0 += U * NT) {
+          uint32_t cv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) { const int k = k0 + u * NT; cv[u] = S.cptr[slot * (d + 1) + (k <= d ? k : d)]; }
+#pragma unroll
+          for (int u = 0; u < U; ++u) { const int k = k0 + u * NT; if (k <= d) cptr[k] = cv[u]; }
+        }
         for (int i = c.tid(); i < p; i += NT) {
           mptr[i] = S.rlo[r0 + i];
           vkind[i] = S.vkind[r0 + i];
         }
         if (c.tid() == 0) mptr[p] = nz;
-        for (uint32_t e = c.tid(); e < nz; e += NT) {
-          if (pm1) {
-            mcol[e] = (uint16_t)(S.ccol[z0 + e] | (S.cval[z0 + e] < 0.f ? 0x8000u : 0u));
-            cvar[e] = (uint16_t)(S.cvar[z0 + e] | (S.cvalc[z0 + e] < 0.f ? 0x8000u : 0u));
-          } else {
-            mcol[e] = S.ccol[z0 + e];
-            mval[e] = S.cval[z0 + e];
-            cvar[e] = S.cvar[z0 + e];
-            cvalc[e] = S.cvalc[z0 + e];
+        const uint32_t elast = nz > 0u ? nz - 1u : 0u;
+        for (uint32_t e0 = c.tid(); e0 < nz; e0 += (uint32_t)(U * NT)) {
+          uint16_t cc[U], cr[U];
+          float cvl[U], crl[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)(u * NT), ec = e < nz ? e : elast;  // clamped: loads are unconditional
+            cc[u] = S.ccol[z0 + ec];
+            cvl[u] = S.cval[z0 + ec];
+            cr[u] = S.cvar[z0 + ec];
+            crl[u] = S.cvalc[z0 + ec];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t e = e0 + (uint32_t)(u * NT);
+            if (e < nz) {
+              if (pm1) {
+                mcol[e] = (uint16_t)(cc[u] | (cvl[u] < 0.f ? 0x8000u : 0u));
+                cvar[e] = (uint16_t)(cr[u] | (crl[u] < 0.f ? 0x8000u : 0u));
+              } else {
+                mcol[e] = cc[u];
+                mval[e] = cvl[u];
+                cvar[e] = cr[u];
+                cvalc[e] = crl[u];
+              }
+            }
           }
         }
       }
