@@ -484,7 +484,11 @@ CAVE_HD double band_weight(uint8_t u, double rk, double inv_mu) {
 // ---- sizing of the one-wave form below (shared with the host code: cone_instance.h, cave_hip.hip)
 constexpr int kBandBlock = 4;      // pivots eliminated per step
 constexpr int kBandWaveDuos = 5;   // duos per lane
-constexpr int kBandWaveRegs = 20;  // prefetch registers per lane: one staged chunk = bw + 1 rows
+constexpr int kBandWaveRegs = 20;  // prefetch registers per lane (factor rows of the back substitution)
+
+constexpr int kBandGroup = 32;     // rows built per call of the row producer
+constexpr int kBandSpinLimit = 1 << 22;  // polls before a wave stops waiting for the other one (never reached: an exit
+                                         // every wave takes even if the hand-over protocol were broken)
 
 CAVE_HOSTDEV int band_wave_duos(int bw) {
   int nd = 0;
@@ -492,30 +496,29 @@ CAVE_HOSTDEV int band_wave_duos(int bw) {
   return nd;
 }
 CAVE_HOSTDEV bool band_wave_fits(int bw, int p) {
-  // Half bandwidths below kBandBlock stay on the team form.  With two waves the rows admitted for step k - 4
-  // (k + bw .. k + bw + 3) are written while wave 0 reads the pivot rows k .. k + 3 of step k: disjoint only for
-  // bw >= 4 (found by the banded inequality cones of tests/test_gpu_round2.py: bw = 3 raced in the 2-wave kernel).
+  // Half bandwidths below kBandBlock stay on the team form.
   if (bw < kBandBlock || p <= bw + 1) return false;
-  if ((bw + 1) * (bw + 1) > 64 * kBandWaveRegs) return false;
+  if (bw + 2 > 64) return false;  // one lane per entry of a row
   return band_wave_duos(bw) <= 64 * kBandWaveDuos;
 }
-// window row stride: odd, so that consecutive rows start on different banks
+// ring row stride: odd, so that consecutive rows start on different banks
 CAVE_HOSTDEV int band_wave_stride(int bw) { return ((bw + 1) & 1) ? bw + 1 : bw + 2; }
-// window entries: a ring of bw + kBandBlock rows (a block of pivot rows + every row the block reaches)
-CAVE_HOSTDEV uint32_t band_wave_window(int bw) { return (uint32_t)(bw + kBandBlock) * (uint32_t)band_wave_stride(bw); }
 // operand scratch of one block step: the pivot rows and the multipliers, kBandBlock entries per column, columns
 // kBandBlock .. bw + kBandBlock + 1 (the last one is a zero column: second operand of a duo without a second entry)
 CAVE_HOSTDEV uint32_t band_wave_scratch(int bw) { return 2u * (uint32_t)kBandBlock * (uint32_t)(bw + kBandBlock + 2); }
-// staging entries: two chunks of bw + 1 raw rows on the way down, a 64-row ring of factor rows on the way back.  The
-// scratch lives in x (unused until the back substitution) when p is large enough, else behind the staging chunks.
-CAVE_HOSTDEV int band_wave_chunk(int bw) { return bw + 1 < 2 * kBandBlock ? 2 * kBandBlock : bw + 1; }  // rows per staged chunk
 // row stride of the factor ring of the back substitution (an even stride would spread the per-lane reads over all
 // banks -- 31 gives 4-way conflicts -- but measured no faster on the 30x30 batch, and costs LDS)
 CAVE_HOSTDEV int band_wave_ring_stride(int bw) { return bw + 1; }
-CAVE_HOSTDEV uint32_t band_wave_staging(int bw, int p) {
-  const uint32_t ld = (uint32_t)bw + 1u, b = 64u * (uint32_t)band_wave_ring_stride(bw) + 1u;
-  uint32_t a = 2u * (uint32_t)band_wave_chunk(bw) * ld;
-  if ((uint32_t)p < band_wave_scratch(bw)) a += band_wave_scratch(bw);
+// Rows of the ring the elimination works in: the bw + kBandBlock rows a step touches plus at least one group the
+// producer is ahead, a multiple of kBandGroup (a group never wraps; neither does a pivot block).
+CAVE_HOSTDEV int band_wave_ring_rows(int bw) { return (bw + kBandBlock + 2 * kBandGroup - 1) / kBandGroup * kBandGroup; }
+// LDS entries of the wave form (SolveWork::bwin): [row ring | one entry: the two words the producer and the
+// eliminator meet through | operand scratch when p is too small for x to hold it]; the back substitution reuses the
+// region for its 64-row ring of factor rows (+ one zero entry).
+CAVE_HOSTDEV uint32_t band_wave_flags_at(int bw) { return (uint32_t)band_wave_ring_rows(bw) * (uint32_t)band_wave_stride(bw); }
+CAVE_HOSTDEV uint32_t band_wave_region(int bw, int p) {
+  const uint32_t a = band_wave_flags_at(bw) + 1u + ((uint32_t)p < band_wave_scratch(bw) ? band_wave_scratch(bw) : 0u);
+  const uint32_t b = 64u * (uint32_t)band_wave_ring_stride(bw) + 1u;
   return a > b ? a : b;
 }
 
@@ -634,60 +637,63 @@ CAVE_NOINLINE __device__ void band_gen_rows(const BandGen* gen_v, const int lane
 //      factor (workspace);
 //   C  every duo of the trailing triangle takes its four updates in one pass: 4 + 4 operand reads whose addresses
 //      never change, one ds_read2_b64 / ds_write2_b64 of the target -- a quarter of the LDS round trips and
-//      of the address arithmetic of a pivot-at-a-time loop (measured on a 30x30 grid: ~1190 cycles per pivot there,
-//      issue- and latency-bound at ~130 instructions per pivot on a lone wave);
-//   D  the right-hand side below the block; E  four new rows take the slots of the four retired ones.
+//      of the address arithmetic of a pivot-at-a-time loop;
+//   D  the right-hand side below the block.
 // Every entry receives the same fma sequence as in a pivot-at-a-time elimination, so the bits are the same.
-// NW = waves in the workgroup.  NW >= 2: wave 0 runs A and B of a step while wave 1 admits the rows of the PREVIOUS
-// step (E), a workgroup barrier, then both waves share C (duo rounds u = wave, wave + 2, ..) and wave 1 does D, a
-// second barrier; waves 2.. only attend the barriers.  The back substitution stays on wave 0.
+//
+// Rows live in ONE ring of RING = 64 or 96 rows (band_wave_ring_rows: the former window and staging buffers in one
+// piece), row r in slot r mod RING, in the form the elimination sees them (shifted diagonal, identity rows of bound
+// rows, zero rows past the end).  NW >= 2: wave 1 is the PRODUCER -- it builds rows kBandGroup at a time (from the cone:
+// band_gen_rows, or from the materialised band) up to RING - (bw + 4) rows ahead of the pivot, wave 0 is the ELIMINATOR
+// and runs A-D alone; they meet through two LDS words (rows produced / rows retired), not through barriers: the stamp
+// build of round 3 showed the two-wave form of round 2 (wave 1 admits rows and shares C, two barriers per step) waiting
+// for wave 1 in 2.4 k of the 4.5 k cycles of a step -- ~1.3 k per step to admit four rows and 11 k cycles per
+// band_gen_rows call every eight steps, all on the critical path.  NW = 1: the one wave produces the next group when the
+// step needs it.  The back substitution stays on wave 0.
 template <int NW>
 CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave_v, const double* Hb_v, const int bw_v,
                                                   const double* rhs_v, const uint8_t* act_v, const int p_v,
                                                   const double reg_rel, double* win_v, double* fac_v, double* z_v,
-                                                  double* x_v, double* stg_v, const BandGen* gen_v = nullptr,
+                                                  double* x_v, const BandGen* gen_v = nullptr,
                                                   unsigned long long* stamps = nullptr) {
-  constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs, NB = kBandBlock;
-  constexpr int NWE = NW >= 2 ? 2 : 1;  // waves that share the elimination
+  constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs, NB = kBandBlock, G = kBandGroup;
+  constexpr bool DUO = NW >= 2;  // a producer wave exists
   const int wave = __builtin_amdgcn_readfirstlane(wave_v);
   const int bw = __builtin_amdgcn_readfirstlane(bw_v), p = __builtin_amdgcn_readfirstlane(p_v);
-  auto bar = [&]() __attribute__((always_inline)) {  // orders the LDS traffic of the waves
-    if constexpr (NW > 1) CAVE_LDS_BARRIER();
-    else CAVE_WAVE_ORDER();
-  };
-  if (wave >= NWE) {
-    bar();
-    for (int k = 0; k < p; k += NB) { bar(); bar(); }
-    return;
+  const bool w0 = wave == 0;
+  double* win_ = uniform_ptr(win_v);
+  auto win = space_cast<3>(win_);
+  const int ld = bw + 1, wl = band_wave_stride(bw), R = bw + NB;
+  const int RING = band_wave_ring_rows(bw), rsz = RING * wl;
+  // the two words the waves meet through: rows [0, prod) have been built, rows [0, cons) have been retired
+  auto flags = reinterpret_cast<typename SpacePtr<int, 3>::type>(win + band_wave_flags_at(bw));
+  if constexpr (DUO) {
+    if (w0 && lane == 0) { CAVE_FLAG_STORE(flags + 0, 0); CAVE_FLAG_STORE(flags + 1, 0); }
+    CAVE_LDS_BARRIER();  // (also: whatever used this LDS before is done with it)
+    if (wave >= 2) return;
   }
-  const bool w0 = wave == 0, wlast = wave == NWE - 1;
   const double* Hb_ = uniform_ptr(Hb_v);
   const double* rhs = uniform_ptr(rhs_v);
   const uint8_t* act_ = uniform_ptr(act_v);
-  double* win_ = uniform_ptr(win_v);
   double* fac_ = uniform_ptr(fac_v);
   double* z_ = uniform_ptr(z_v);
   double* x_ = uniform_ptr(x_v);
-  double* stg_ = uniform_ptr(stg_v);
   const BandGen* gen = uniform_ptr(gen_v);
   const bool hgen = gen != nullptr && gen->on;  // rows of H on demand (no bound rows): Hb is not read
 #ifdef CAVE_STAMPS
   struct { unsigned long long* st; } c{stamps};
 #endif
   CAVE_T0();
-  const int ld = bw + 1, wl = band_wave_stride(bw), CH = band_wave_chunk(bw), csz = CH * ld, R = bw + NB, wsz = R * wl;
   auto Hb = space_cast<1>(Hb_);
   auto fac = space_cast<1>(fac_);
   auto act = space_cast<3>(act_);
-  auto win = space_cast<3>(win_);
   auto z = space_cast<3>(z_);
   auto x = space_cast<3>(x_);
-  auto stg = space_cast<3>(stg_);
   // operand scratch: P[a][t] = U[k+a][k+t], Q[a][t] = P[a][t] / d_a, t = NB .. bw + NB + 1 (last column: zeros).
   // Component-major: the lanes of a duo round read consecutive t, i.e. consecutive words (as [t][a] records the
   // same reads were 16-way bank conflicts: rocprof counted 1.0e9 conflict cycles per launch on the 30x30 batch)
   const int ncol = bw + NB + 2;
-  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : stg + 2 * csz;  // (csz = one staged chunk)
+  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 1);
   auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;
@@ -700,76 +706,86 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     nfix = wave_sum_u32(nfix);
   } else md = gen->hdiag;
   const double reg = reg_rel * md;
-  // rows first .. first + n - 1 of H into dst (a real call: band_gen_rows has its own register allocation)
-  auto gen_rows = [&](const int first, const int n, decltype(win) dst, const int stride) __attribute__((always_inline)) {
-    band_gen_rows(gen, lane, p, bw, first, n, (double*)dst, stride);
-    CAVE_WAVE_ORDER();
-  };
-  if (w0)
-    for (int i = lane; i < p; i += 64) {
-      double zi = rhs[i];
-      if (nfix != 0u && !act[i]) {
-        const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
-        for (int j = j0; j <= j1; ++j)
-          if (act[j]) zi -= ((i >= j) ? Hb[j * ld + (i - j)] : Hb[i * ld + (j - i)]) * rhs[j];
-      }
-      z[i] = zi;
-    }
-  double regs[RMAX];
-  auto fetch = [&](decltype(Hb) src, int e0, int eend) {  // unconditional loads from clamped indices
-#pragma unroll
-    for (int j = 0; j < RMAX; ++j) {
-      int e = e0 + lane + j * 64;
-      e = e < eend ? e : eend - 1;
-      regs[j] = src[e > 0 ? e : 0];
-    }
-  };
-  auto park = [&](int b) {
-#pragma unroll
-    for (int j = 0; j < RMAX; ++j) {
-      const int idx = lane + j * 64;
-      if (idx < csz) stg[b * csz + idx] = regs[j];
-    }
-  };
-  // rows 0 .. R-1 of the band as the elimination sees them (rows past the end of the matrix are zero rows)
-  if (hgen) {
-    if (w0) {
-      gen_rows(0, R, win, wl);
-      if (lane < R && lane < p) win[lane * wl] += reg;
-    }
-  } else
-  for (int idx = lane + 64 * wave; idx < wsz; idx += 64 * NWE) {
-    const int r = idx / wl, t = idx - r * wl;
-    win[idx] = (t <= bw) ? band_row_entry(Hb, ld, act, p, reg, r, t) : 0.0;
-  }
-  // chunk c = raw rows R + c*CH .. of H; chunk c is consumed from buffer c & 1 (the wave that admits rows stages them)
-  if (wlast) {
-    if (hgen) {
-      gen_rows(R, CH, stg, ld);
-      gen_rows(R + CH, CH, stg + csz, ld);
+  // rows first .. first + G - 1 into their slots (first is a multiple of G, RING too: a group never wraps)
+  auto produce = [&](const int first, const int slot) __attribute__((always_inline)) {
+    auto dst = win + slot * wl;
+    if (hgen) {  // (a real call: band_gen_rows has its own register allocation; it zeroes wl entries per row)
+      band_gen_rows(gen, lane, p, bw, first, G, (double*)dst, wl);
+      CAVE_WAVE_ORDER();
+      if (lane < G && first + lane < p) dst[lane * wl] += reg;
     } else {
-      fetch(Hb, R * ld, p * ld);
-      park(0);
-      fetch(Hb, (R + CH) * ld, p * ld);
-      park(1);
-      fetch(Hb, (R + 2 * CH) * ld, p * ld);
+      // lane = entry of the row, eight rows per batch.  All loads first, from clamped addresses, and the masks as
+      // selects: written with an `if`, each row pays two dependent round trips (the loads are sunk into the branch)
+      const int tl = lane <= bw ? lane : bw;
+      constexpr int RB = 8;
+      for (int r0 = 0; r0 < G; r0 += RB) {
+        double raw[RB];
+        uint32_t fI[RB], fJ[RB];
+#pragma unroll
+        for (int a = 0; a < RB; ++a) {
+          const int rI = first + r0 + a;
+          const int rc = rI < p ? rI : p - 1;
+          raw[a] = Hb[rc * ld + tl];
+          fI[a] = act[rc];
+          fJ[a] = act[rI + tl < p ? rI + tl : p - 1];
+        }
+#pragma unroll
+        for (int a = 0; a < RB; ++a) {
+          const int rI = first + r0 + a;
+          const bool fixed = (fI[a] | fJ[a]) != 0u;
+          const double diag = fI[a] != 0u ? 1.0 : raw[a] + reg;
+          double v = (lane == 0) ? diag : (fixed ? 0.0 : raw[a]);
+          v = (rI + tl < p && lane <= bw) ? v : 0.0;
+          if (lane < wl) dst[(r0 + a) * wl + lane] = v;
+        }
+      }
     }
+  };
+  // last pivot block: the elimination reads rows below p_last + R
+  const int p_last = ((p - 1) / NB) * NB;
+  if constexpr (DUO) {
+    if (!w0) {  // ---- the producer
+      const int p_end = (p_last + R + G - 1) / G * G;
+      int slot = 0;
+      for (int g = 0; g < p_end; g += G) {
+        const int need = g + G - RING;  // rows [g, g + G) take the slots of rows [g - RING, g + G - RING)
+        if (need > 0) {
+          for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+            if (__builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 1)) >= need) break;
+            CAVE_SPIN_PAUSE();
+          }
+          CAVE_WAVE_ORDER();
+        }
+        produce(g, slot);
+        CAVE_LDS_WAIT();
+        slot += G;
+        slot = slot >= RING ? 0 : slot;
+        if (lane == 0) CAVE_FLAG_STORE(flags + 0, g + G);
+      }
+      return;
+    }
+  }
+  for (int i = lane; i < p; i += 64) {
+    double zi = rhs[i];
+    if (nfix != 0u && !act[i]) {
+      const int j0 = i - bw > 0 ? i - bw : 0, j1 = i + bw < p - 1 ? i + bw : p - 1;
+      for (int j = j0; j <= j1; ++j)
+        if (act[j]) zi -= ((i >= j) ? Hb[j * ld + (i - j)] : Hb[i * ld + (j - i)]) * rhs[j];
+    }
+    z[i] = zi;
   }
   // this wave's duos: duo q in row-major order over rows s = 1 .. bw below the block (entries t = s, s+2, ...);
-  // round u = duos 64u .. 64u + 63, dealt to wave u % NWE.  A lane past the end of the last round repeats a duo of
-  // the same round: two lanes of one wave then store the same bits to the same address (all loads of a step precede
-  // its stores), which needs no predicate.
+  // round u = duos 64u .. 64u + 63.  A lane past the end of the last round repeats a duo of the same round: two lanes
+  // then store the same bits to the same address (all loads of a step precede its stores), which needs no predicate.
   int uq[U], up[U], ur[U];
   const int nd = band_wave_duos(bw);
   const int nu = (nd + 63) / 64;
-  const int nuw = nu > wave ? (nu - wave + NWE - 1) / NWE : 0;
   {
 #pragma unroll
     for (int i = 0; i < U; ++i) {
-      const int u = wave + NWE * i;
-      int nv = nd - 64 * u;
+      int nv = nd - 64 * i;
       nv = nv > 64 ? 64 : (nv < 1 ? 1 : nv);
-      int q = 64 * u + (lane < nv ? lane : lane % nv), s = 1;
+      int q = 64 * i + (lane < nv ? lane : lane % nv), s = 1;
       q = q < nd ? q : 0;
       while (q >= (bw - s + 2) / 2) { q -= (bw - s + 2) / 2; ++s; }
       const int t = s + 2 * q;
@@ -779,68 +795,53 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     }
   }
   // zero column of the scratch, written once
-  if (w0 && lane < NB) { scrP[lane * ncol + ncol - 1] = 0.0; scrQ[lane * ncol + ncol - 1] = 0.0; }
-  bar();
+  if (lane < NB) { scrP[lane * ncol + ncol - 1] = 0.0; scrQ[lane * ncol + ncol - 1] = 0.0; }
+  CAVE_WAVE_ORDER();
   CAVE_ACC(10);
   auto eliminate = [&](auto nu_tag) __attribute__((always_inline)) {
     constexpr int NU = decltype(nu_tag)::value;
-    int slot_k = 0, cidx = 0, cpos = 0;
+    int slot_k = 0;        // slot of row k (RING is a multiple of NB: a block never wraps)
+    int have = 0, hslot = 0;  // rows built so far (DUO: as last seen in the producer's word)
     const bool zl = lane == 63;
-    // ---- E: rows kk + R .. kk + R + 3 take the slots (first: slot_e) of the four rows retired by step kk.  All loads first, from clamped
-      // addresses, and the masks as selects: written with an `if`, each row pays two dependent LDS round trips
-      // (the loads are sunk into the branch) -- measured at ~490 cycles per row, more than the elimination itself.
-    auto admit = [&](const int kk, const int slot_e) __attribute__((always_inline)) {
-        const int tl = lane <= bw ? lane : bw;
-        double raw[NB];
-        uint32_t fI[NB], fJ[NB];
-        int dst[NB];
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-          int cp = cpos + a, cb = cidx;
-          if (cp >= CH) { cp -= CH; ++cb; }
-          int sl = slot_e + a;
-          sl = sl >= R ? sl - R : sl;
-          dst[a] = sl * wl + tl;
-          const int rI = kk + R + a;
-          raw[a] = stg[(cb & 1) * csz + cp * ld + tl];
-          fI[a] = act[rI < p ? rI : p - 1];
-          fJ[a] = act[rI + tl < p ? rI + tl : p - 1];
-        }
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-          const int rI = kk + R + a;
-          const bool fixed = (fI[a] | fJ[a]) != 0u;
-          const double diag = fI[a] != 0u ? 1.0 : raw[a] + reg;
-          double v = (lane == 0) ? diag : (fixed ? 0.0 : raw[a]);
-          v = (rI + tl < p) ? v : 0.0;
-          if (lane <= bw) win[dst[a]] = v;
-        }
-        cpos += NB;
-        if (cpos >= CH) {  // into chunk cidx + 1: chunk cidx + 2 (registers) takes the buffer chunk cidx has left
-          cpos -= CH;
-          ++cidx;
-          CAVE_WAVE_ORDER();  // ... once every lane has read its last rows out of that buffer
-          if (hgen) gen_rows(R + (cidx + 1) * CH, CH, stg + ((cidx + 1) & 1) * csz, ld);
-          else {
-            park((cidx + 1) & 1);
-            fetch(Hb, (R + (cidx + 2) * CH) * ld, p * ld);
-          }
-        }
-      };
     for (int k = 0; k < p; k += NB) {
-      double zq[NB] = {0.0, 0.0, 0.0, 0.0};
-      if (w0) {
+      // rows k .. k + R - 1 are resident before the step touches them
+      if constexpr (DUO) {
+        if (have < k + R) {
+          for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+            have = __builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 0));
+            if (have >= k + R) break;
+            CAVE_SPIN_PAUSE();
+          }
+          CAVE_WAVE_ORDER();
+        }
+      } else {
+        while (have < k + R) {
+          produce(have, hslot);
+          have += G;
+          hslot += G;
+          hslot = hslot >= RING ? 0 : hslot;
+          CAVE_WAVE_ORDER();
+        }
+      }
       // ---- A: pivot rows k .. k+3 into registers; lane t holds column k + t (entry t - a of row k + a)
-      double u[NB];
+      double u[NB], uz[NB];
 #pragma unroll
-      for (int a = 0; a < NB; ++a) {
-        int sl = slot_k + a;
-        sl = sl >= R ? sl - R : sl;
+      for (int a = 0; a < NB; ++a) {  // all eight loads, then the selects (pinned: see CAVE_PIN_F64)
         const int off = lane - a;
         const bool in = off >= 0 && off <= bw;
-        const double v = win[sl * wl + (in ? off : 0)];
-        const double zv = z[k + a < p ? k + a : p - 1];
-        u[a] = zl ? (k + a < p ? zv : 0.0) : (in ? v : 0.0);
+        u[a] = win[(slot_k + a) * wl + (in ? off : 0)];
+        uz[a] = z[k + a < p ? k + a : p - 1];
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a) { CAVE_PIN_F64(u[a]); CAVE_PIN_F64(uz[a]); }
+      if constexpr (DUO) {  // the four slots are free once these loads have executed (a wave's LDS operations do so in order)
+        if (lane == 0) CAVE_FLAG_STORE(flags + 1, k + NB);
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        const int off = lane - a;
+        const bool in = off >= 0 && off <= bw;
+        u[a] = zl ? (k + a < p ? uz[a] : 0.0) : (in ? u[a] : 0.0);
       }
       double inv[NB];
 #pragma unroll
@@ -865,6 +866,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
           scrQ[a * ncol + lane] = u[a] * inv[a];
         }
       }
+      double zq[NB];
 #pragma unroll
       for (int a = 0; a < NB; ++a) {
         zq[a] = readlane_f64(u[a], 63);
@@ -876,18 +878,8 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         for (int a = 0; a < NB; ++a)
           if (k + a < p) z[k + a] = u[a];
       }
-      }  // w0
-      if constexpr (NWE > 1) {
-        if (!w0 && k > 0) admit(k - NB, slot_k >= NB ? slot_k - NB : slot_k - NB + R);
-      }
-      bar();
+      CAVE_WAVE_ORDER();
       CAVE_ACCF(1);
-      if constexpr (NWE > 1) {
-        if (!w0) {  // the right-hand side entries wave 0 has just finished
-#pragma unroll
-          for (int a = 0; a < NB; ++a) zq[a] = z[k + a < p ? k + a : p - 1];
-        }
-      }
       // ---- C: trailing triangle
       const int base_k = slot_k * wl;
       double qv[NU > 0 ? NU : 1][NB], p0[NU > 0 ? NU : 1][NB], p1[NU > 0 ? NU : 1][NB], r0[NU > 0 ? NU : 1], r1[NU > 0 ? NU : 1];
@@ -895,7 +887,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
         int o = base_k + ur[i];
-        o = o >= wsz ? o - wsz : o;
+        o = o >= rsz ? o - rsz : o;
         poff[i] = o;
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
@@ -907,7 +899,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         r1[i] = win[o + 1];
       }
       // ---- D: right-hand side below the block (lane i: row k + NB + i)
-      const bool zown = wlast && lane < bw && k + NB + lane < p;
+      const bool zown = lane < bw && k + NB + lane < p;
       double zqv[NB];
 #pragma unroll
       for (int a = 0; a < NB; ++a) zqv[a] = scrQ[a * ncol + NB + (lane < bw ? lane : 0)];
@@ -929,14 +921,12 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       for (int a = 0; a < NB; ++a) zz = fma(-zqv[a], zq[a], zz);
       if (zown) z[k + NB + lane] = zz;
       CAVE_ACCF(9);
-      if constexpr (NWE == 1) admit(k, slot_k);
       slot_k += NB;
-      slot_k = slot_k >= R ? slot_k - R : slot_k;
-      bar();
-      CAVE_ACCF(11);
+      slot_k = slot_k >= RING ? 0 : slot_k;
+      CAVE_WAVE_ORDER();
     }
   };
-  switch (nuw) {
+  switch (nu) {
     case 0: eliminate(std::integral_constant<int, 0>{}); break;
     case 1: eliminate(std::integral_constant<int, 1>{}); break;
     case 2: eliminate(std::integral_constant<int, 2>{}); break;
@@ -944,13 +934,15 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
     case 4: eliminate(std::integral_constant<int, 4>{}); break;
     default: eliminate(std::integral_constant<int, 5>{}); break;
   }
-  if (!w0) return;
   // the factor rows go out through this wave's stores and come back through its loads
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   CAVE_ACC(11);
 #ifdef CAVE_STAMPS
   c.st[13] += (unsigned long long)p;  // pivots eliminated (per-pivot cost = slot 11 / slot 13)
+#ifdef CAVE_STAMPS_FINE
+  if (NWE > 1 && p >= 512) { c.st[8] += (unsigned long long)x[400]; c.st[7] += (unsigned long long)x[401]; }
+#endif
 #endif
   // ---- back substitution  x_k = inv_k (z_k - sum_s U[k][k+s] x_{k+s}), column oriented.
   // Factor rows come back through a 64-row ring in LDS (row r in slot r & 63; one zero entry behind the ring), so lane l
@@ -958,8 +950,9 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   // the band is redirected to the zero entry.  Rows are fetched CHB at a time (registers: lane = entry,
   // register = row), a chunk ahead, and parked once the rows that used their slots are done.
   constexpr int CHB = RMAX;
+  double regs[RMAX];
   const int rs = band_wave_ring_stride(bw), zero_at = 64 * rs;
-  auto ring = stg;
+  auto ring = win;  // (the row ring of the elimination is free now)
   ring[zero_at] = 0.0;
   const int tl = lane < ld ? lane : bw;
   auto fetch_b = [&](int chi) {  // rows chi, chi-1, .. of the factor

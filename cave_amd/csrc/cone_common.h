@@ -50,6 +50,27 @@
 #define CAVE_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// Words two waves of a workgroup meet through (LDS): relaxed atomic accesses the compiler neither caches nor moves
+// across the ordering points around them; a wave that polls one pauses between two looks (the SIMT emulation: the
+// readfirstlane around the load is a rendezvous, which hands the processor to the other waves).
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+#define CAVE_FLAG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define CAVE_FLAG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define CAVE_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+#else
+#define CAVE_FLAG_LOAD(p) (*(volatile int*)(p))
+#define CAVE_FLAG_STORE(p, v) (*(volatile int*)(p) = (v))
+#define CAVE_SPIN_PAUSE() do {} while (0)
+#endif
+
+// A loaded value the compiler must materialise HERE (it otherwise sinks a load into the branch that selects it, and
+// a batch of independent LDS reads becomes a chain of round trips).  No code is emitted.
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+#define CAVE_PIN_F64(x) asm volatile("" : "+v"(x))
+#else
+#define CAVE_PIN_F64(x) do {} while (0)
+#endif
+
 // ---- optional phase timing (diagnostic builds only: -DCAVE_STAMPS; never in the shipped library).
 // Cycle deltas are summed in per-wave registers (WaveCtx::st) and stored once per instance.
 #if defined(CAVE_STAMPS) && defined(__HIPCC__)

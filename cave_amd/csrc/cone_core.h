@@ -1310,7 +1310,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         if constexpr (BAND) {
 #if defined(CAVE_GPU_CODE)
           if (w.band_wave) {
-            solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg,
+            solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step,
                                            &w.gen
 #ifdef CAVE_STAMPS
                                   , c.st
@@ -1629,7 +1629,7 @@ CAVE_HD SolveResult solve_cone_ipm_impl(C& c, const SolveView& v, SolveWork& w, 
         for (int i = c.tid(); i < p; i += NT) w.step[i] = w.dn.x[w.dn.pos[i]];
       } else {
 #if defined(CAVE_GPU_CODE)
-        if (w.band_wave) solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, w.g2, w.act, p, 1e-12, w.bwin, w.bfac, w.bz, w.step, w.bstg, nullptr);
+        if (w.band_wave) solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, w.g2, w.act, p, 1e-12, w.bwin, w.bfac, w.bz, w.step, nullptr);
         else
 #endif
         if (w.band_hot) solve_spd_band<C, true>(c, w.H, w.bw, w.g2, w.act, p, 1e-12, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);

@@ -231,14 +231,14 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       bool wave_mode = false;
 #if defined(CAVE_GPU_CODE) && !defined(CAVE_NO_BAND_WAVE)  // (diagnostic builds can pin the team form of the band solver)
       if constexpr (C::WL == 64) {
-        const uint64_t need = 8ull * (band_wave_window(bw) + 2ull * pp + band_wave_staging(bw, p)) + pp + 64u;
+        const uint64_t need = 8ull * (band_wave_region(bw, p) + 2ull * pp) + pp + 64u;
         wave_mode = hot != nullptr && band_wave_fits(bw, p) && (uint64_t)(hot->top - hot->off) >= need;
       }
 #endif
       // small, touched every elimination step / every inner round: LDS first
       if (w.dn.on) wave_mode = false;
       if (!w.dn.on) {
-      w.bwin = hot_get<double>(hot, ar, wave_mode ? band_wave_window(bw) : ld * ld);
+      w.bwin = hot_get<double>(hot, ar, wave_mode ? band_wave_region(bw, p) : ld * ld);  // (wave form: ring + staging in one piece)
       w.bz = hot_get<double>(hot, ar, pp);
       }
       w.step = hot_get<double>(hot, ar, pp);
@@ -252,7 +252,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       }
       if (!w.dn.on) {
 #if defined(CAVE_GPU_CODE)
-      if (wave_mode) w.bstg = hot_get<double>(hot, ar, band_wave_staging(bw, p));
+      if (wave_mode) w.bstg = w.bwin;  // (not used by the wave form)
       else
 #endif
       w.bstg = hot_get<double>(hot, ar, 2u * (uint32_t)w.bch * ld);
@@ -798,7 +798,7 @@ static inline uint32_t packed_large_lds_bytes(int64_t max_rows, int64_t max_bw) 
     if (tot <= kMaxLds) return (uint32_t)tot;
   }
   if (band_wave_fits((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) {
-    const uint64_t need = 8ull * (band_wave_window((int)max_bw) + 2ull * p + band_wave_staging((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p))) + p + 64u;
+    const uint64_t need = 8ull * (band_wave_region((int)max_bw, (int)(p > 0x7fffffff ? 0x7fffffff : p)) + 2ull * p) + p + 64u;
     const uint64_t tot = ((need + 256u + 64u) + 255u) & ~255ull;  // + context scratch, alignment slack
     if (tot * 4u <= kMaxLds) return (uint32_t)tot;
   }
