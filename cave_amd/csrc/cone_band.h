@@ -512,14 +512,16 @@ CAVE_HOSTDEV int band_wave_ring_stride(int bw) { return bw + 1; }
 // Rows of the ring the elimination works in: the bw + kBandBlock rows a step touches plus at least one group the
 // producer is ahead, a multiple of kBandGroup (a group never wraps; neither does a pivot block).
 CAVE_HOSTDEV int band_wave_ring_rows(int bw) { return (bw + kBandBlock + 2 * kBandGroup - 1) / kBandGroup * kBandGroup; }
-// LDS entries of the wave form (SolveWork::bwin): [row ring | one entry: the two words the producer and the
+// LDS entries of the wave form (SolveWork::bwin): [row ring | two entries: the four words the producer and the
 // eliminator meet through | operand scratch when p is too small for x to hold it]; the back substitution reuses the
-// region for its 64-row ring of factor rows (+ one zero entry).
-CAVE_HOSTDEV uint32_t band_wave_flags_at(int bw) { return (uint32_t)band_wave_ring_rows(bw) * (uint32_t)band_wave_stride(bw); }
-CAVE_HOSTDEV uint32_t band_wave_region(int bw, int p) {
-  const uint32_t a = band_wave_flags_at(bw) + 1u + ((uint32_t)p < band_wave_scratch(bw) ? band_wave_scratch(bw) : 0u);
+// front of the region for its 64-row ring of factor rows (+ one zero entry).
+CAVE_HOSTDEV uint32_t band_wave_flags_at(int bw) {  // (behind the row ring and behind the factor ring + its zero entry)
+  const uint32_t a = (uint32_t)band_wave_ring_rows(bw) * (uint32_t)band_wave_stride(bw);
   const uint32_t b = 64u * (uint32_t)band_wave_ring_stride(bw) + 1u;
   return a > b ? a : b;
+}
+CAVE_HOSTDEV uint32_t band_wave_region(int bw, int p) {
+  return band_wave_flags_at(bw) + 2u + ((uint32_t)p < band_wave_scratch(bw) ? band_wave_scratch(bw) : 0u);
 }
 
 #if defined(CAVE_GPU_CODE)
@@ -665,10 +667,15 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   auto win = space_cast<3>(win_);
   const int ld = bw + 1, wl = band_wave_stride(bw), R = bw + NB;
   const int RING = band_wave_ring_rows(bw), rsz = RING * wl;
-  // the two words the waves meet through: rows [0, prod) have been built, rows [0, cons) have been retired
+  // the words the waves meet through.  Elimination: rows [0, flags[0]) have been built, rows [0, flags[1]) retired
   auto flags = reinterpret_cast<typename SpacePtr<int, 3>::type>(win + band_wave_flags_at(bw));
   if constexpr (DUO) {
-    if (w0 && lane == 0) { CAVE_FLAG_STORE(flags + 0, 0); CAVE_FLAG_STORE(flags + 1, 0); }
+    if (w0 && lane == 0) {
+      CAVE_FLAG_STORE(flags + 0, 0);
+      CAVE_FLAG_STORE(flags + 1, 0);
+      CAVE_FLAG_STORE(flags + 2, 0x7fffffff);  // back substitution: lowest factor row in its ring (not started)
+      CAVE_FLAG_STORE(flags + 3, 0x7fffffff);  // back substitution: the row being solved
+    }
     CAVE_LDS_BARRIER();  // (also: whatever used this LDS before is done with it)
     if (wave >= 2) return;
   }
@@ -693,7 +700,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   // Component-major: the lanes of a duo round read consecutive t, i.e. consecutive words (as [t][a] records the
   // same reads were 16-way bank conflicts: rocprof counted 1.0e9 conflict cycles per launch on the 30x30 batch)
   const int ncol = bw + NB + 2;
-  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 1);
+  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 2);
   auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;
@@ -761,6 +768,48 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         slot += G;
         slot = slot >= RING ? 0 : slot;
         if (lane == 0) CAVE_FLAG_STORE(flags + 0, g + G);
+      }
+      // ---- then the factor rows of the back substitution, top row first, into the 64-row ring (row r: slot r & 63).
+      // Two batches of BR rows in registers (lane = entry): the loads of one are in flight while the other waits
+      // for its slots -- row r may take the slot of row r + 64 once the substitution has passed that row.
+      for (int spin = 0; spin < kBandSpinLimit; ++spin) {  // the eliminator's stores have completed (its fence)
+        if (__builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 2)) <= p) break;
+        CAVE_SPIN_PAUSE();
+      }
+      CAVE_WAVE_ORDER();
+      constexpr int BR = 16;
+      const int rs = band_wave_ring_stride(bw);
+      const int tl = lane < ld ? lane : bw;
+      double ra[BR], rb[BR];
+      auto loadb = [&](double* rg, const int top) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < BR; ++j) rg[j] = fac[(top - j > 0 ? top - j : 0) * ld + tl];
+      };
+      auto storeb = [&](const double* rg, const int top) __attribute__((always_inline)) {
+        const int lowest = top - (BR - 1) > 0 ? top - (BR - 1) : 0;
+        for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+          if (__builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 3)) < lowest + 64) break;
+          CAVE_SPIN_PAUSE();
+        }
+        CAVE_WAVE_ORDER();
+        if (lane < ld) {
+#pragma unroll
+          for (int j = 0; j < BR; ++j)
+            if (top - j >= 0) win[((top - j) & 63) * rs + lane] = rg[j];
+        }
+        CAVE_LDS_WAIT();
+        if (lane == 0) CAVE_FLAG_STORE(flags + 2, lowest);
+      };
+      int top = p - 1;
+      loadb(ra, top);
+      while (top >= 0) {
+        if (top - BR >= 0) loadb(rb, top - BR);
+        storeb(ra, top);
+        top -= BR;
+        if (top < 0) break;
+        if (top - BR >= 0) loadb(ra, top - BR);
+        storeb(rb, top);
+        top -= BR;
       }
       return;
     }
@@ -940,9 +989,6 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   CAVE_ACC(11);
 #ifdef CAVE_STAMPS
   c.st[13] += (unsigned long long)p;  // pivots eliminated (per-pivot cost = slot 11 / slot 13)
-#ifdef CAVE_STAMPS_FINE
-  if (NWE > 1 && p >= 512) { c.st[8] += (unsigned long long)x[400]; c.st[7] += (unsigned long long)x[401]; }
-#endif
 #endif
   // ---- back substitution  x_k = inv_k (z_k - sum_s U[k][k+s] x_{k+s}), column oriented.
   // Factor rows come back through a 64-row ring in LDS (row r in slot r & 63; one zero entry behind the ring), so lane l
@@ -969,23 +1015,42 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         if (chi - j >= 0) ring[((chi - j) & 63) * rs + lane] = regs[j];
     }
   };
-  int chi_next = p - 1;  // top row of the chunk in flight
-  fetch_b(chi_next);
-  while (chi_next >= 0 && chi_next + bw + NB >= p - 1) {
-    park_b(chi_next);
-    chi_next -= CHB;
-    if (chi_next >= 0) fetch_b(chi_next);
+  int chi_next = p - 1;  // NW = 1: top row of the chunk in flight; NW >= 2: lowest row the producer has delivered
+  if constexpr (DUO) {
+    chi_next = p;
+    if (lane == 0) { CAVE_FLAG_STORE(flags + 3, p - 1); CAVE_FLAG_STORE(flags + 2, p); }  // (in this order: starts the producer)
+  } else {
+    fetch_b(chi_next);
+    while (chi_next >= 0 && chi_next + bw + NB >= p - 1) {
+      park_b(chi_next);
+      chi_next -= CHB;
+      if (chi_next >= 0) fetch_b(chi_next);
+    }
   }
   CAVE_WAVE_ORDER();
   {
     double acc = 0.0;  // partial sum of the row this lane owns (row = lane mod 64)
     const int rowbase = lane * rs;
-    auto admit = [&](int k) __attribute__((always_inline)) {  // rows chi_next .. enter the ring before their first use
-      if (chi_next >= 0 && k <= chi_next + bw + NB) {
-        park_b(chi_next);
-        chi_next -= CHB;
-        if (chi_next >= 0) fetch_b(chi_next);
-        CAVE_WAVE_ORDER();
+    // rows k - bw - NB .. are in the ring before step k reads them
+    auto admit = [&](int k) __attribute__((always_inline)) {
+      if constexpr (DUO) {
+        if (lane == 0) CAVE_FLAG_STORE(flags + 3, k);  // rows above k are done with: their slots are free
+        const int need = k - bw - NB > 0 ? k - bw - NB : 0;
+        if (chi_next > need) {
+          for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+            chi_next = __builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 2));
+            if (chi_next <= need) break;
+            CAVE_SPIN_PAUSE();
+          }
+          CAVE_WAVE_ORDER();
+        }
+      } else {
+        if (chi_next >= 0 && k <= chi_next + bw + NB) {
+          park_b(chi_next);
+          chi_next -= CHB;
+          if (chi_next >= 0) fetch_b(chi_next);
+          CAVE_WAVE_ORDER();
+        }
       }
     };
     // entry t of factor row r, zero past the band (scalar address: every lane reads the same word)
