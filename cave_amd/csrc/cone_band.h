@@ -896,9 +896,10 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
 #pragma unroll
       for (int a = 0; a < NB; ++a) {
         const double d = readlane_f64(u[a], a);
-        const bool ok = d > 1e-300;
-        double iv = rcp_full(ok ? d : 1.0);
-        iv = ok ? iv : 0.0;
+        // (no select in FRONT of the reciprocal: a dropped pivot gives inf / NaN there and 0 here, and the chain of a
+        // kept one loses a VALU -> SALU -> VALU round trip)
+        double iv = rcp_full(d);
+        iv = d > 1e-300 ? iv : 0.0;
         inv[a] = iv;
 #pragma unroll
         for (int b = a + 1; b < NB; ++b) {

@@ -426,11 +426,18 @@ CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double
 // kLongRow entries are summed by one whole wave each.
 
 template <class C, bool PM1> CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double* rc, double* g);
+template <class C, bool PM1> CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const double* rc, double* g);
 
 template <class C, bool PM1, bool STREAMED = false>
 CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
   constexpr int TEAM = C::TEAM;
   constexpr int RPP = C::NT / TEAM;  // rows per pass
+  if constexpr (STREAMED && C::WL > 1 && TEAM == 4) {  // large-cone path: the cone is in global memory
+    gradient_short_rows_streamed<C, PM1>(c, v, rc, g);
+    gradient_long_rows_streamed<C, PM1>(c, v, rc, g);
+    c.sync();
+    return;
+  }
   const int sub = c.tid() % TEAM;
   for (int base = 0; base < v.p; base += RPP) {
     const int i = base + c.tid() / TEAM;
@@ -978,6 +985,80 @@ CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double*
     if (lane == 0) {
       g[i0] = part0;
       if (two) g[i1] = part1;
+    }
+  }
+}
+
+// Short rows (at most kLongRow entries): ONE LANE PER ROW, R rows per thread in flight -- the extents of all of them,
+// then their first four entries, then the operands: three memory latencies per R * NT rows, where the four-lanes-per-row
+// loop of gradient() pays three per NT / 4 rows (30x30 grid, 900 rows on 128 threads: 29 passes, 134 k cycles per
+// gradient -- 10 % of the kernel).  The four partial sums of a row and their order are those of that loop and its quad
+// reduction (entries s, s + 4, .. in partial sum s; (p0 + p1) + (p2 + p3)), so the bits are the same.  A real call:
+// its ~100 live registers would otherwise spill inside the Newton iteration.
+template <class C, bool PM1>
+CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const double* rc, double* g) {
+  constexpr int R = 8, Q = 4, NT = C::NT;
+  static_assert(C::TEAM == Q, "partial sums follow the quad reduction of gradient()");
+  const int p = v.p, tid = c.tid();
+  const uint32_t* mptr = v.mptr;
+  const uint32_t last = mptr[p] > 0u ? mptr[p] - 1u : 0u;
+  for (int i0 = tid; i0 < p; i0 += R * NT) {
+    uint32_t lo[R], n[R], col[R][Q];
+    double val[R][Q], x[R][Q];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int i = i0 + u * NT;
+      const int ic = i < p ? i : p - 1;
+      lo[u] = mptr[ic];
+      n[u] = mptr[ic + 1] - lo[u];
+      if (i >= p || n[u] > kLongRow) n[u] = 0u;  // (long rows: gradient_long_rows_streamed)
+    }
+    uint32_t any = 0u;
+#pragma unroll
+    for (int u = 0; u < R; ++u) any |= n[u];
+    if (any == 0u) {  // long or empty rows only (TSP degree / cut rows): nothing to fetch
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int i = i0 + u * NT;
+        if (i < p && mptr[i + 1] == mptr[i]) g[i] = 0.0;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const uint32_t e = lo[u] + (uint32_t)q < last ? lo[u] + (uint32_t)q : last;  // clamped, unconditional
+        csr_entry<PM1>(v, e, col[u][q], val[u][q]);
+      }
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) x[u][q] = rc[col[u][q]];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int i = i0 + u * NT;
+      double part[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        part[q] = 0.0;
+        if ((uint32_t)q < n[u]) part[q] -= val[u][q] * x[u][q];
+      }
+      for (uint32_t off = (uint32_t)Q; off < n[u]; off += (uint32_t)Q) {  // rows with more than four entries
+        uint32_t c2[Q];
+        double v2[Q], x2[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const uint32_t e = lo[u] + off + (uint32_t)q < last ? lo[u] + off + (uint32_t)q : last;
+          csr_entry<PM1>(v, e, c2[q], v2[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) x2[q] = rc[c2[q]];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (off + (uint32_t)q < n[u]) part[q] -= v2[q] * x2[q];
+      }
+      if (i < p && (n[u] != 0u || mptr[i + 1] - mptr[i] <= kLongRow)) g[i] = (part[0] + part[1]) + (part[2] + part[3]);
     }
   }
 }

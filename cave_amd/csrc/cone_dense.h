@@ -188,25 +188,36 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
       if (wave == 0) {
         double u[NB][2], zv[NB], inv[NB];
 #pragma unroll
-        for (int a = 0; a < NB; ++a) {
+        for (int a = 0; a < NB; ++a) {  // all twelve loads, then the selects (pinned: see CAVE_PIN_F64)
           const int row = k0 + a;
           const int rb = fold_base(p, row < p ? row : p - 1);
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
             const int col = k0 + lane + 64 * g;
             const bool in = row < p && col >= row && col < p;
-            const double val = A[in ? rb + (col - row) : 0];
-            u[a][g] = in ? val : 0.0;
+            u[a][g] = A[in ? rb + (col - row) : 0];
           }
-          const double zr = z[row < p ? row : p - 1];
-          zv[a] = row < p ? zr : 0.0;
+          zv[a] = z[row < p ? row : p - 1];
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) { CAVE_PIN_F64(u[a][0]); CAVE_PIN_F64(u[a][1]); CAVE_PIN_F64(zv[a]); }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          const int row = k0 + a;
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int col = k0 + lane + 64 * g;
+            const bool in = row < p && col >= row && col < p;
+            u[a][g] = in ? u[a][g] : 0.0;
+          }
+          zv[a] = row < p ? zv[a] : 0.0;
         }
 #pragma unroll
         for (int a = 0; a < NB; ++a) {
           const double dk = readlane_f64(u[a][0], a);
           const bool ok = (k0 + a < nF) && dk > 1e-300;
-          double iv = rcp_full(ok ? dk : 1.0);  // v_rcp_f64 + two Newton steps (a third of the IEEE divide)
-          iv = ok ? iv : 0.0;
+          double iv = rcp_full(dk);  // v_rcp_f64 + two Newton steps (a third of the IEEE divide); no select in front
+          iv = ok ? iv : 0.0;        // of it (cone_band.h): a dropped pivot gives inf / NaN there and 0 here
           inv[a] = iv;
 #pragma unroll
           for (int b = a + 1; b < NB; ++b) {

@@ -187,6 +187,9 @@ def stream_mark(device=None) -> "torch.cuda.Event":
     return ev
 
 
+PIPE_PACK_WAVES = 4  # wave shape of the pack kernel on the side stream (1 / 2 / 4 / 8)
+
+
 def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = None) -> "PreparedCones | torch.Tensor":
     """Start the pack stage for a dense batch on the side stream.  Returns the tensor itself when the shape does
     not qualify for the split form (the loss call then takes the ordinary path).
@@ -222,7 +225,7 @@ def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = N
         side.wait_event(ready)
     ctrs.record_stream(side)
     with torch.cuda.stream(side):
-        rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, 0, 0, 4, ss.ref, 0, _lib.ptr(ss.pack_status),
+        rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, 0, 0, PIPE_PACK_WAVES, ss.ref, 0, _lib.ptr(ss.pack_status),
                                     C_void(side.cuda_stream))
         _lib.check(rc, "cave_hip_pack_fill (slot mode, side stream)")
         ev = torch.cuda.Event()
