@@ -54,9 +54,12 @@ def parse(argv=None):
                     help="skip the side measurements at the instance sizes of BASELINE configs 3-5")
     ap.add_argument("--no-large-cpu", action="store_true",
                     help="skip the one-instance CPU timing of the 30x30 grid in other_configs (about a minute of host time)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="overlap the pack stage of step i+1 (side stream) with the solve stage of step i "
-                         "(measured r03: 206 vs 176 us/step -- the two kernels slow each other down; off by default)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the pack and the solve stage of a step back to back on one stream.  Default: software "
+                         "pipeline across steps -- the pack stage of step i+1 (side stream, launched behind a ~10 us "
+                         "spacer so that the solve's workgroups take their residency first) runs beside the solve "
+                         "stage of step i; every timed step still launches exactly one pack and one solve")
+    ap.add_argument("--pipeline", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at --gpus 1 (world size 1) and run the per-step "
                          "[sum loss, count] all-reduce and the sharded-store leg: the code path of an N-GPU run")
@@ -275,11 +278,13 @@ def main(argv=None):
     red = torch.zeros(2, device=dev)
 
     from cave_amd.qpsolver import PreparedCones, cone_op_prepared, prepare_dense, stream_mark
+    args.pipeline = not args.no_pipeline
 
-    # Optional software pipeline across steps (--pipeline): the pack stage of step i+1 (stream the dense cones of the
-    # NEXT batch, build its reduced cones: depends on the cones only, which a DataLoader has collated ahead of the
-    # predictor) runs on a side stream while step i's solve kernel runs; every timed step still launches exactly one
-    # pack and one solve.  Default: the two stages back to back on one stream.
+    # Software pipeline across steps (default; --no-pipeline: the two stages back to back on one stream): the pack stage
+    # of step i+1 (stream the dense cones of the NEXT batch, build its reduced cones: depends on the cones only, which a
+    # DataLoader has collated ahead of the predictor) runs on a side stream while step i's solve kernel runs; every
+    # timed step still launches exactly one pack and one solve (the pack launched by the last timed step is for a
+    # batch nobody solves: extra work inside the timed region, none skipped).
     state = {"prep": None}
 
     def step(i):
@@ -348,7 +353,11 @@ def main(argv=None):
         m_i = (np.abs(ctrs_np[bids]).sum(axis=2) > 0).sum(axis=1)
         alg.append(int((4 * m_i * d).sum() + B * (4 * d + 4 * d + 4)))
     alg_bytes = int(np.mean(alg))
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    step_ms = 1e3 * dt / args.steps
+    pipelined = bool(args.pipeline and split)
+    # roofline of the step: the two kernels of consecutive steps overlap in the pipelined form, so the per-launch cost
+    # of the pair is the step time of the timed region (HIP-event time of an isolated call: kernel_ms)
+    achieved = alg_bytes / ((step_ms if pipelined else kern_ms) * 1e-3) / 1e9
 
     traffic, traffic_src = None, None  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/diag/pmc_run.sh)
     try:
@@ -370,16 +379,21 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernels, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
-                         "kernel_ms_note": "HIP events around one operator call = every kernel of the step (the split "
-                                           "form launches two); per-kernel durations: profiles/r03_kernel_stats.csv",
+                         "frac_isolated_call": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_note": "kernel_ms: HIP events around ONE isolated operator call = every kernel of the "
+                                           "step back to back (the split form launches two); achieved / frac: "
+                                           + ("algorithmic bytes / step time of the timed region (pack of step i+1 beside "
+                                              "the solve of step i)" if pipelined else "algorithmic bytes / kernel_ms")
+                                           + "; per-kernel durations: profiles/r03_kernel_stats.csv",
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
-            "pipeline": {"across_steps": bool(args.pipeline and split),
+            "pipeline": {"across_steps": pipelined,
                          "unpipelined_ms_per_step": kern_ms,
-                         "note": "--pipeline overlaps the pack stage of step i+1 with the solve stage of step i on a side "
-                                 "stream (cave_amd.qpsolver.prepare_dense); measured r03: SLOWER (206 vs 176 us per step): "
-                                 "co-resident, the two kernels slow each other down; off by default."},
+                         "note": "the pack stage of step i+1 runs on a side stream beside the solve stage of step i "
+                                 "(cave_amd.qpsolver.prepare_dense(next, ready=stream_mark())), behind a ~10 us spacer "
+                                 "kernel so that the solve is dispatched first and keeps its residency; every timed step "
+                                 "launches one pack and one solve; --no-pipeline runs them back to back"},
         }
         if use_dist:
             res["process_group"] = {"backend": "nccl (RCCL)", "world_size": world,

@@ -188,6 +188,11 @@ def stream_mark(device=None) -> "torch.cuda.Event":
 
 
 PIPE_PACK_WAVES = 4  # wave shape of the pack kernel on the side stream (1 / 2 / 4 / 8)
+# Cycles (torch.cuda._sleep) a one-workgroup spin kernel holds the side stream back behind `ready` (0 = off; ~10 us).  The pack and the solve it is to
+# overlap with become runnable at the same moment; whichever kernel is dispatched first takes the residency of the
+# machine (both fill it: 4 workgroups per CU), and the other one then runs AFTER it instead of beside it.  The spacer
+# lets the solve -- one or two queue packets behind the mark -- go first; the pack then fills what the solve leaves.
+PIPE_SPACER_CYCLES = 25000
 
 
 def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = None) -> "PreparedCones | torch.Tensor":
@@ -225,6 +230,8 @@ def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = N
         side.wait_event(ready)
     ctrs.record_stream(side)
     with torch.cuda.stream(side):
+        if ready is not None and PIPE_SPACER_CYCLES > 0:
+            torch.cuda._sleep(PIPE_SPACER_CYCLES)
         rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, 0, 0, PIPE_PACK_WAVES, ss.ref, 0, _lib.ptr(ss.pack_status),
                                     C_void(side.cuda_stream))
         _lib.check(rc, "cave_hip_pack_fill (slot mode, side stream)")
