@@ -60,6 +60,9 @@ def parse(argv=None):
                          "spacer so that the solve's workgroups take their residency first) runs beside the solve "
                          "stage of step i; every timed step still launches exactly one pack and one solve")
     ap.add_argument("--pipeline", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="batches the pack stage runs ahead of the solve: 1 or 2 (a DataLoader prefetch depth of 2; the slot "
+                         "pool of prepare_dense holds 3 stores)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at --gpus 1 (world size 1) and run the per-step "
                          "[sum loss, count] all-reduce and the sharded-store leg: the code path of an N-GPU run")
@@ -285,20 +288,26 @@ def main(argv=None):
     # DataLoader has collated ahead of the predictor) runs on a side stream while step i's solve kernel runs; every
     # timed step still launches exactly one pack and one solve (the pack launched by the last timed step is for a
     # batch nobody solves: extra work inside the timed region, none skipped).
-    state = {"prep": None}
+    state = {"q": []}
+    depth = max(1, min(2, args.pipeline_depth))  # prepared batches ahead of the solve (the slot pool holds 3 stores)
 
     def step(i):
         _, _, c, p = batches[i % R]
         if args.pipeline:
-            prep = state["prep"] if state["prep"] is not None else prepare_dense(c)
+            q = state["q"]
+            if not q:  # first step: the batches the pipeline is ahead by
+                q.append(prepare_dense(c))
+                for a in range(1, depth):
+                    q.append(prepare_dense(batches[(i + a) % R][2]))
+            prep = q.pop(0)
             mark = stream_mark(dev)
             if isinstance(prep, PreparedCones):
                 o = cone_op_prepared(prep, p, mode, -1.0, 0.2, check=False, outputs=outs)
             else:
                 o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
-            # enqueued AFTER the solve: the solve's workgroups take their residency first, the pack of the next
+            # enqueued AFTER the solve: the solve's workgroups take their residency first, the pack of a later
             # batch fills what is left of each CU (one 4-wave workgroup next to four one-wave solve workgroups)
-            state["prep"] = prepare_dense(batches[(i + 1) % R][2], ready=mark)
+            q.append(prepare_dense(batches[(i + depth) % R][2], ready=mark))
         else:
             o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
         if use_dist and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
@@ -388,7 +397,7 @@ def main(argv=None):
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
-            "pipeline": {"across_steps": pipelined,
+            "pipeline": {"across_steps": pipelined, "depth": depth if pipelined else 0,
                          "unpipelined_ms_per_step": kern_ms,
                          "note": "the pack stage of step i+1 runs on a side stream beside the solve stage of step i "
                                  "(cave_amd.qpsolver.prepare_dense(next, ready=stream_mark())), behind a ~10 us spacer "
