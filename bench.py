@@ -29,6 +29,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto a few hardware queues (4 unless told otherwise).  With an RCCL communicator alive its streams
+# take part in that mapping and the side stream of the pack stage lands on the SAME queue as the stream of the solve:
+# the two kernels then run one after the other (195 us per step instead of 130; tools/diag/dist_step_cost.py).
+# Read by the HIP runtime when it initialises, i.e. after this line in every rank.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
@@ -278,7 +283,9 @@ def main(argv=None):
     B, m_max, d = ctrs.shape
     mode = {"project": _lib.MODE_PROJECT, "exact": _lib.MODE_EXACT, "inner": _lib.MODE_INNER}[args.mode]
     outs = ("proj", "rnorm") if mode == _lib.MODE_PROJECT else ("loss", "grad")
-    red = torch.zeros(2, device=dev)
+    reds = [torch.zeros(2, device=dev) for _ in range(4)]
+    count = torch.full((1,), float(args.batch), device=dev)
+    red_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     from cave_amd.qpsolver import PreparedCones, cone_op_prepared, prepare_dense, stream_mark
     args.pipeline = not args.no_pipeline
@@ -311,9 +318,17 @@ def main(argv=None):
         else:
             o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
         if use_dist and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
-            red[0] = o["loss"].sum()
-            red[1] = float(B)
-            dist.all_reduce(red)
+            # on a stream of its own behind this step's solve: the next solve depends on neither the sum nor the
+            # collective (RCCL orders the all-reduce after the work of the stream that is current at the call)
+            ev = torch.cuda.Event()
+            ev.record()
+            r = reds[i % len(reds)]
+            with torch.cuda.stream(red_stream):
+                red_stream.wait_event(ev)
+                o["loss"].record_stream(red_stream)
+                torch.sum(o["loss"], dim=0, keepdim=True, out=r[0:1])  # (device side: `r[0] = x.sum(); r[1] = float(B)`
+                r[1:2].copy_(count)                                    #  copies scalars from pageable host memory, which
+                dist.all_reduce(r)                                     #  waits for the stream: 240 us per step)
         return o
 
     # one status-checked call per rotating batch: lets the wrapper settle a launch shape that fits every cone of the run

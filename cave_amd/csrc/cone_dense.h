@@ -184,6 +184,7 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
     constexpr int NWV = NT / 64;
     const int pc = p + 4;
     auto scP = space_cast<3>(dw.scr), scQ = space_cast<3>(dw.scr) + NB * pc;
+    CAVE_T0();
     for (int k0 = 0; k0 < nF; k0 += NB) {
       if (wave == 0) {
         double u[NB][2], zv[NB], inv[NB];
@@ -249,7 +250,9 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
           dinv[k0 + lane] = lane == 0 ? inv[0] : (lane == 1 ? inv[1] : (lane == 2 ? inv[2] : inv[3]));
         }
       }
+      CAVE_ACCF(0);
       c.sync_lds();
+      CAVE_ACCF(1);
       {
         const int cb = k0 + NB;       // first trailing row / column
         const int c0 = cb + 2 * lane; // this lane's columns c0, c0 + 1 (past p - 1: the zero columns)
@@ -301,7 +304,9 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
           z[r] = zz;
         }
       }
+      CAVE_ACCF(9);
       c.sync_lds();
+      CAVE_ACCF(5);
     }
     return;
   }
