@@ -26,9 +26,9 @@ mean = a.mean(0); tot = mean[14]
 rt = a[:, 15] / 100.0
 print("per-instance time (us) quantiles 0/50/90/99/100:", [round(float(np.quantile(rt, q))) for q in (0, .5, .9, .99, 1)], "slowest instances:", np.argsort(rt)[-5:].tolist(), "their iters", o["iters"].cpu().numpy()[np.argsort(rt)[-5:]].tolist())
 print(f"{which} B={B}: iters mean {o['iters'].float().mean():.2f}; cycles/instance {tot:.0f} = {mean[15]/100:.1f} us")
-if "fine" in os.environ.get("STAMPS_SO", "") and mean[13] == 0:
+if "fine" in os.environ.get("STAMPS_SO", "") and which != "sp30":
     print(f"  dense LDL^T fine stamps (cycles per instance): pivot block on wave 0 {mean[0]:.0f}  wait at barrier 1 {mean[1]:.0f}  trailing update {mean[9]:.0f}  wait at barrier 2 {mean[5]:.0f}")
-if "fine" in os.environ.get("STAMPS_SO", "") and mean[13] > 0:
+if "fine" in os.environ.get("STAMPS_SO", "") and which == "sp30":
     print(f"  per pivot (fine stamps): block A {mean[0]/mean[13]:.0f}  B {mean[1]/mean[13]:.0f}  C+D {mean[9]/mean[13]:.0f}  E {mean[11]/mean[13]:.0f}")
 if mean[13] > 0: print(f"  per pivot: factor {mean[11]/mean[13]:.0f} cycles, back-subst {mean[12]/mean[13]:.0f} cycles")
 for i, n in enumerate(names):
