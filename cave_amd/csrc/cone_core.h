@@ -1100,11 +1100,19 @@ CAVE_HD void gather_mt_streamed(C& c, const SolveView& v, const float* base, con
 #pragma unroll
       for (int e = 0; e < E; ++e)
         if ((uint32_t)e < cnt[u]) acc += sgn * x[u][e] * t[u][e];
-      for (uint32_t e = (uint32_t)E; e < cnt[u]; ++e) {  // columns with more than E entries
-        uint32_t var;
-        double val;
-        csc_entry<PM1>(v, lo[u] + e, var, val);
-        acc += sgn * val * th[var];
+      for (uint32_t e0 = (uint32_t)E; e0 < cnt[u]; e0 += 4u) {  // columns with more than E entries (edges inside
+        uint32_t var[4];                                         // several cuts): four at a time, loads first -- one
+        double val[4], tv[4];                                    // entry per trip paid two memory latencies per entry
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+          const uint32_t ee = lo[u] + e0 + j < last ? lo[u] + e0 + j : last;
+          csc_entry<PM1>(v, ee, var[j], val[j]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) tv[j] = th[var[j]];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+          if (e0 + j < cnt[u]) acc += sgn * val[j] * tv[j];
       }
       out[k] = acc;
     }

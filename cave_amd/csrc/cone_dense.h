@@ -102,7 +102,10 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const Dense
   // share a row (the edges of one TSP node) add to the same diagonal entry: the LDS serialises those adds (a few
   // hundred cycles per instruction, measured cheaper than the 8x line requests of a blocked column assignment), and
   // integer adds give the same sum in any order.
-  constexpr int G = 4, E = 4;
+  // E = 8: an edge inside c subtour cuts has 2 + c entries; with E = 4 the entries past the fourth took a loop of
+  // dependent global loads per PAIR, and the instances with three to five large cuts -- the slowest of a TSP-100 batch,
+  // i.e. the kernel time -- spent 410 k cycles per Hessian there against 110 k for the median instance.
+  constexpr int G = 4, E = 8;
   const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
   for (int kb = c.tid(); kb < d; kb += G * NT) {
     uint32_t lo[G], cnt[G], a[G][E];

@@ -33,3 +33,15 @@ if "fine" in os.environ.get("STAMPS_SO", "") and which == "sp30":
 if mean[13] > 0: print(f"  per pivot: factor {mean[11]/mean[13]:.0f} cycles, back-subst {mean[12]/mean[13]:.0f} cycles")
 for i, n in enumerate(names):
     print(f"  {n:45s} {mean[i]:12.0f}  {100*mean[i]/tot:5.1f}%")
+
+order = np.argsort(rt)
+sel = list(order[-3:][::-1]) + [order[len(order) // 2]]
+nnz = None
+try:
+    nnz = st.n_nnz.cpu().numpy() if hasattr(st, "n_nnz") else None
+except Exception:
+    pass
+print("  per-instance phases (cycles): slowest three, then the median instance")
+for b in sel:
+    row = a[b]
+    print(f"    inst {b:4d} iters {int(o['iters'][b])} total {row[14]:9.0f}: grad {row[2]:8.0f} hess {row[3]:8.0f} inner(incl. solve) {row[4]:8.0f} [factor {row[11]:8.0f} backsub {row[12]:7.0f}] ls-setup {row[6]:7.0f} ls-loop {row[7]:7.0f} resid {row[8]:7.0f} other {row[14] - row[2] - row[3] - row[4] - row[5] - row[6] - row[7] - row[8]:8.0f}")
