@@ -150,6 +150,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
                                  uint8_t* warm_state = nullptr) {
   const int d = v.d;
   const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER || mode == MODE_IPM);
+  CAVE_T0();  // (stamp builds, large path: slot 0 = set-up before the solver, 1 = the solver call, 9 = epilogue)
   int32_t st = ST_OK;
   double f = 0.0;
   const bool empty = (v.n_valid == 0);
@@ -187,7 +188,16 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.gen.on = false;
       {  // fixed-point scale of the Hessian accumulation: |H_ab| <= (largest entry)^2 * (longest row)
         double vm = v.pm1 ? 1.0 : 0.0, ml = 1.0;
-        if (!v.pm1) for (uint32_t e = c.tid(); e < v.mptr[p]; e += C::NT) vm = fmax(vm, fabs((double)v.mval[e]));
+        if (!v.pm1) {  // (eight entries per thread in flight: the values are in global memory on this path)
+          const uint32_t nz = v.mptr[p];
+          for (uint32_t e0 = c.tid(); e0 < nz; e0 += 8u * (uint32_t)C::NT) {
+            float mv[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) mv[j] = v.mval[e0 + j * (uint32_t)C::NT < nz ? e0 + j * (uint32_t)C::NT : nz - 1u];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) vm = fmax(vm, fabs((double)mv[j]));
+          }
+        }
         for (int i = c.tid(); i < p; i += C::NT) ml = fmax(ml, (double)(v.mptr[i + 1] - v.mptr[i]));
         vm = c.reduce_max(vm);
         ml = c.reduce_max(ml);
@@ -409,10 +419,12 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       }
     }
 #endif
+    if constexpr (LARGE) CAVE_ACC(0);
     if (!lite) {
       if constexpr (LARGE) solve_cone_band_call(c, vv, w, max_iter, 1e-11, &r);
       else r = solve_cone<C, false>(c, vv, w, max_iter, 1e-11);
     }
+    if constexpr (LARGE) CAVE_ACC(1);
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
@@ -433,6 +445,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
   eo.loss = o.loss ? o.loss + b : nullptr;
   eo.grad = o.grad ? o.grad + b * d : nullptr;
   epilogue(c, mode, d, sign, inner_ratio, empty, y, res, f, avg, tvec, eo);
+  if constexpr (LARGE) CAVE_ACC(9);
   return st;
 }
 

@@ -44,4 +44,4 @@ except Exception:
 print("  per-instance phases (cycles): slowest three, then the median instance")
 for b in sel:
     row = a[b]
-    print(f"    inst {b:4d} iters {int(o['iters'][b])} total {row[14]:9.0f}: grad {row[2]:8.0f} hess {row[3]:8.0f} inner(incl. solve) {row[4]:8.0f} [factor {row[11]:8.0f} backsub {row[12]:7.0f}] ls-setup {row[6]:7.0f} ls-loop {row[7]:7.0f} resid {row[8]:7.0f} other {row[14] - row[2] - row[3] - row[4] - row[5] - row[6] - row[7] - row[8]:8.0f}")
+    print(f"    inst {b:4d} [set-up {row[0]:8.0f} solver call {row[1]:9.0f} epilogue {row[9]:8.0f}] iters {int(o['iters'][b])} total {row[14]:9.0f}: grad {row[2]:8.0f} hess {row[3]:8.0f} inner(incl. solve) {row[4]:8.0f} [factor {row[11]:8.0f} backsub {row[12]:7.0f}] ls-setup {row[6]:7.0f} ls-loop {row[7]:7.0f} resid {row[8]:7.0f} other {row[14] - row[2] - row[3] - row[4] - row[5] - row[6] - row[7] - row[8]:8.0f}")
