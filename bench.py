@@ -64,7 +64,9 @@ def parse(argv=None):
                          "pipeline across steps -- the pack stage of step i+1 (side stream, launched behind a ~10 us "
                          "spacer so that the solve's workgroups take their residency first) runs beside the solve "
                          "stage of step i; every timed step still launches exactly one pack and one solve")
-    ap.add_argument("--pipeline", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="force the pipelined form (default: pipelined unless the untimed self-check before the warm-up "
+                         "finds the back-to-back form faster on this machine)")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches the pack stage runs ahead of the solve: 1 or 2 (a DataLoader prefetch depth of 2; the slot "
                          "pool of prepare_dense holds 3 stores)")
@@ -288,6 +290,7 @@ def main(argv=None):
     red_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
     from cave_amd.qpsolver import PreparedCones, cone_op_prepared, prepare_dense, stream_mark
+    args.pipeline_forced = bool(args.pipeline)   # --pipeline: no self-check, always pipelined
     args.pipeline = not args.no_pipeline
 
     # Software pipeline across steps (default; --no-pipeline: the two stages back to back on one stream): the pack stage
@@ -334,6 +337,28 @@ def main(argv=None):
     # one status-checked call per rotating batch: lets the wrapper settle a launch shape that fits every cone of the run
     for _, _, c_, p_ in batches:
         cone_op_dense(c_, p_, mode, -1.0, 0.2, outputs=outs)
+    # Self-check of the pipelined form (untimed): it only pays when the solve is dispatched ahead of the pack and the two
+    # streams sit on different hardware queues -- properties of the runtime's queue mapping, not of this code.  24 steps of
+    # each form; the timed region uses the pipeline only where it is the faster one here (`pipeline.self_check`).
+    self_check = None
+    if args.pipeline and not args.pipeline_forced:
+        def probe(n=24):
+            state["q"] = []
+            for i in range(4):
+                step(i)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n):
+                step(i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+        t_pipe = probe()
+        args.pipeline = False
+        t_b2b = probe()
+        args.pipeline = t_pipe < t_b2b
+        self_check = {"pipelined_us_per_step": 1e6 * t_pipe, "back_to_back_us_per_step": 1e6 * t_b2b,
+                      "chosen": "pipelined" if args.pipeline else "back to back"}
+        state["q"] = []
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -412,7 +437,7 @@ def main(argv=None):
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
-            "pipeline": {"across_steps": pipelined, "depth": depth if pipelined else 0,
+            "pipeline": {"across_steps": pipelined, "depth": depth if pipelined else 0, "self_check": self_check,
                          "unpipelined_ms_per_step": kern_ms,
                          "note": "the pack stage of step i+1 runs on a side stream beside the solve stage of step i "
                                  "(cave_amd.qpsolver.prepare_dense(next, ready=stream_mark())), behind a ~10 us spacer "
