@@ -230,8 +230,8 @@ def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = N
         side.wait_event(ready)
     ctrs.record_stream(side)
     with torch.cuda.stream(side):
-        if ready is not None and PIPE_SPACER_CYCLES > 0:
-            torch.cuda._sleep(PIPE_SPACER_CYCLES)
+        if ready is not None and PIPE_SPACER_CYCLES > 0 and hasattr(torch.cuda, "_sleep"):
+            torch.cuda._sleep(PIPE_SPACER_CYCLES)  # (PyTorch's own spin kernel: one workgroup)
         rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, 0, 0, PIPE_PACK_WAVES, ss.ref, 0, _lib.ptr(ss.pack_status),
                                     C_void(side.cuda_stream))
         _lib.check(rc, "cave_hip_pack_fill (slot mode, side stream)")
