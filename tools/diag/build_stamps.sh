@@ -1,8 +1,9 @@
 #!/bin/bash
 # Diagnostic build with per-phase cycle stamps (-DCAVE_STAMPS).  Never ship or time this build:
 # read its phase SHARES only (tools/diag/run_stamps.py).  A unity build (one translation unit: the stamp
-# buffer is a single __device__ array); UNITS limits it to the kernel shapes a diagnosis needs, e.g.
-#   UNITS="k_pack_w4 k_packed_w1" bash tools/diag/build_stamps.sh
+# buffer is a single __device__ array) of every kernel shape: ~3.5 minutes (the host code references every launch
+# function, so a subset of the shapes does not load).  EXTRA_FLAGS=-DCAVE_STAMPS_FINE adds the per-block-step stamps of
+# the band / dense factorisations; OUT names the library.
 cd "$(dirname "$0")/../.." || exit 1
 ALL="k_dense_w1 k_dense_w2 k_dense_w4 k_dense_w8 k_pack_w1 k_pack_w2 k_pack_w4 k_pack_w8 k_packed_w1 k_packed_w2 k_packed_w4 k_packed_w8 k_large_dense k_large_pack k_large_packed_w1 k_large_packed_w2 k_large_packed_w4"
 U=tools/diag/_unity_stamps.hip
