@@ -698,7 +698,9 @@ CAVE_HD void run_packed_large_instance(C& c, unsigned char* smem, const PackedPa
       if (c.tid() == 0) mptr[p] = nz;
       c.sync();
       SolveView v;
-      v.d = d; v.p = p; v.n_valid = S.n_valid[slot]; v.pm1 = false;
+      // flags bit 1 (set by the host for stores of this path): the indices of this all-+-1 instance carry the signs in
+      // bit 15, the value arrays are not read
+      v.d = d; v.p = p; v.n_valid = S.n_valid[slot]; v.pm1 = (S.flags[slot] & 2) != 0;
       v.mptr = mptr; v.mcol = S.ccol + z0; v.mval = S.cval + z0; v.vkind = S.vkind + r0;
       v.cptr = S.cptr + slot * (d + 1); v.cvar = S.cvar + z0; v.cvalc = S.cvalc + z0; v.usign = S.usign + slot * d;
       v.nlong = 0; v.longrow = nullptr;

@@ -119,7 +119,9 @@ int32_t cave_hip_pack_count(const float* ctrs, int64_t B, int64_t m_max, int64_t
 /* Packed store: structure-of-arrays, all device pointers, filled by cave_hip_pack_fill.
  *   row_off [n+1], nnz_off [n+1]  exclusive prefix sums of the pass-1 counts (int64)
  *   n_valid [n]        rows kept by the projection (0 = empty cone)
- *   flags   [n]        bit0: every reduced-row entry is +-1 (kernels then keep signs in the indices)
+ *   flags   [n]        bit0: every reduced-row entry is +-1 (kernels then keep signs in the indices);
+ *                      bit1 (set by the HOST on stores of the large-cone path, which reads them in place): ccol / cvar of
+ *                      this instance already carry the sign in bit 15 (d, rows < 32768), cval / cvalc are not read
  *   usign   [n*d]      bit0: a +e_k row exists, bit1: a -e_k row exists
  *   avg     [n*d]      _average_ctrs of the instance (static, precomputed)
  *   vkind   [R]        1 = free multiplier (a +a/-a pair), 0 = non-negative     R = row_off[n]

@@ -245,3 +245,40 @@ def test_training_example_with_the_interior_point_inner_mode_on_30x30_grids():
                                "--inner", "ipm", "--max-iter", "3"])
     assert all(np.isfinite(h[1]) for h in hist[1:])
     assert hist[-1][1] < hist[1][1] and hist[-1][2] <= hist[0][2] + 1e-9, hist
+
+
+@pytest.mark.gpu
+def test_large_stores_carry_the_signs_in_their_indices():
+    """The large-cone path reads the store in place in every Newton iteration.  For all-+-1 instances the host folds
+    the sign of every entry into bit 15 of its 16-bit index (`ConeStore._fold_signs`, flags bit 1) and the kernels
+    never load the fp32 value arrays: same outputs as the unfolded store, which a mixed store (one instance with a
+    scaled row: not +-1, left as it is) checks instance by instance against the oracle."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+    from oracle import cave_oracle as O
+
+    dev = torch.device("cuda")
+    ctrs, costs, _ = synth.sp_batch(12, 12, 6, seed=3)
+    ctrs = ctrs.copy()
+    r = int(np.flatnonzero(np.abs(ctrs[5]).sum(axis=1) > 1.5)[0])
+    ctrs[5, r] *= 2.0  # instance 5: one general row scaled (same cone, entries no longer +-1)
+    store = ConeStore.from_dense(torch.tensor(ctrs, device=dev), chunk=6)
+    assert store.large
+    t = store.t
+    flags = t["flags"].cpu().numpy()
+    assert (flags[:5] & 3 == 3).all() and (flags[5] & 3) == 0
+    nnz_off = t["nnz_off"].cpu().numpy()
+    for idx, val in (("ccol", "cval"), ("cvar", "cvalc")):
+        ix = t[idx].cpu().numpy().view(np.uint16)
+        vv = t[val].cpu().numpy()
+        z5 = int(nnz_off[5])
+        assert ((ix[:z5] >> 15).astype(bool) == (vv[:z5] < 0)).all()          # folded instances: bit 15 = sign
+        assert (ix[z5:int(nnz_off[6])] >> 15 == 0).all()                       # the general instance: plain indices
+    o = store.cone_op(torch.arange(6, device=dev), torch.tensor(costs, device=dev), MODE_PROJECT, -1.0, 0.2,
+                      outputs=("proj", "rnorm"))
+    assert bool((o["status"] == 0).all())
+    po, ro = O.batch_project(-costs, ctrs)  # (sign -1: the operator projects -pred)
+    tol = 4e-6 * max(1.0, float(np.abs(costs).max()))
+    assert np.abs(o["proj"].cpu().numpy() - po).max() <= tol and np.abs(o["rnorm"].cpu().numpy() - ro).max() <= tol
