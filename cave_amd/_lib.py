@@ -17,12 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libcave_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
-_HEADERS = [os.path.join(_CSRC, n) for n in ("kernels.h", "cone_common.h", "cone_core.h", "cone_band.h", "cone_dense.h", "cone_instance.h",
+_HEADERS = [os.path.join(_CSRC, n) for n in ("kernels.h", "cone_common.h", "cone_core.h", "cone_band.h", "cone_dense.h", "cone_instance.h", "cone_step.h",
                                              "wave_prims.h", "ctx_wave.h", "ctx_block.h")] + \
     [os.path.join(_ROOT, "include", "cave_hip.h")]
 # translation units: the C ABI (host code) + one file per kernel shape (cave_amd/csrc/kernels.h)
 _UNITS = ["cave_hip"] + [f"k_{op}_w{w}" for op in ("dense", "pack", "packed") for w in (1, 2, 4, 8)] + \
-    ["k_large_dense", "k_large_pack", "k_large_packed_w1", "k_large_packed_w2", "k_large_packed_w4"]
+    ["k_large_dense", "k_large_pack", "k_large_packed_w1", "k_large_packed_w2", "k_large_packed_w4", "k_step"]
 _SOURCES = [os.path.join(_CSRC, u + ".hip") for u in _UNITS] + _HEADERS
 _OBJ_DIR = os.path.join(_CSRC, "build")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC"]
@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "cave_hip_packed_lds_bytes",
     "cave_hip_large_slice_bytes", "cave_hip_packed_large_slice_bytes", "cave_hip_cone_dense_large",
     "cave_hip_pack_large", "cave_hip_cone_packed_large", "cave_hip_packed_large_lds_bytes",
+    "cave_hip_step_lds_bytes", "cave_hip_cone_step",
 )
 
 
@@ -91,6 +92,15 @@ class Store(C.Structure):
     ]
 
 
+class LiteStore(C.Structure):
+    """struct cave_lite_store (include/cave_hip.h): transient per-batch store of the fused step kernel."""
+    _fields_ = [
+        ("n", C.c_int64), ("d", C.c_int32), ("reserved", C.c_int32),
+        ("hdr", C.c_void_p), ("usign", C.c_void_p), ("avg", C.c_void_p), ("rowptr", C.c_void_p),
+        ("ell", C.c_void_p), ("csr16", C.c_void_p), ("rl", C.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -136,6 +146,11 @@ def load_library() -> C.CDLL:
                                                vp, vp, vp, vp, vp, vp, vp, vp]
     for name in ("cave_hip_cone_dense_large", "cave_hip_pack_large", "cave_hip_cone_packed_large"):
         getattr(lib, name).restype = C.c_int32
+    lib.cave_hip_step_lds_bytes.argtypes = [i64, i64]
+    lib.cave_hip_step_lds_bytes.restype = i32
+    lib.cave_hip_cone_step.argtypes = [C.POINTER(LiteStore), vp, i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp,
+                                       vp, i64, i64, i64, C.POINTER(LiteStore), vp, vp, vp]
+    lib.cave_hip_cone_step.restype = i32
     _lib = lib
     return lib
 

@@ -146,12 +146,21 @@ class abstractConeAlignedCosine(optModule):
         return 0.0
 
     @staticmethod
-    def prepare(tight_ctrs: torch.Tensor, ready=None):
-        """Start the prediction-independent half of the forward pass (streaming the dense cones and building the
-        reduced cones) for a batch that will be used in a later call: `nxt = loss_fn.prepare(next_bctr)` while the
-        current step runs, then `loss_fn(cp, nxt)`.  Returns an object to pass in place of `tight_ctrs`
-        (the tensor itself when the shape does not qualify).  `ready`: see qpsolver.prepare_dense / stream_mark."""
-        return prepare_dense(tight_ctrs, ready)
+    def prepare(tight_ctrs: torch.Tensor, following: "torch.Tensor | None" = None):
+        """Run the prediction-independent half of the forward pass (streaming the dense cones and building the
+        reduced cones) for a batch now; pass the result in place of `tight_ctrs`: `loss_fn(cp, prep)`.  With
+        `following` (the dense cones of the batch after it -- the DataLoader has collated them already) that batch's
+        half rides in the launch of this batch's loss call, beside its solve, and `prep.next` is what to pass for it:
+
+            prep = loss_fn.prepare(bctr_0, bctr_1)
+            loss = loss_fn(cp_0, prep); nxt = prep.next.then(bctr_2); loss = loss_fn(cp_1, nxt); ...
+
+        (`cave_amd.dataset.prefetch(loader)` does this wiring around a DataLoader.)  Returns the tensor itself when
+        the shape does not qualify."""
+        prep = prepare_dense(tight_ctrs)
+        if following is not None and isinstance(prep, PreparedCones):
+            prep.then(following)
+        return prep
 
     def _solver_kwargs_for_call(self) -> dict:
         return self.solver_kwargs

@@ -283,4 +283,76 @@ int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* 
   return CAVE_OK;
 }
 
+// ------------------------------------------------------------------ fused step
+
+static int32_t step_limits(int64_t m_max, int64_t d, int32_t& cap, int32_t& lds) {
+  if (m_max < 0 || d <= 0 || d > kLiteMaxD || m_max > 32767) return CAVE_E_INVALID;
+  cap = 0;
+  uint64_t pack_lds = 0;
+  if (m_max > 0) {
+    // non-zeros kept per instance: structured cones carry <= d unit entries + a few sparse rows (cone_instance.h
+    // default_limits); the arena of the two-wave pack half: no dump slots behind the scan output, no prediction
+    int64_t c = 4 * (m_max + d) + 128;
+    if (c > m_max * d) c = m_max * d;
+    if (c < 64) c = 64;
+    cap = (int32_t)c;
+    pack_lds = arena_bytes_dense(m_max, d, c, 64, 32, c * 6 / 10, 0, true, false) - align8u(4 * d);
+  }
+  const uint32_t solve_lds = step_solve_lds_bytes(d);
+  uint32_t need = pack_lds > solve_lds ? (uint32_t)pack_lds : solve_lds;
+  need = (need + 255u) & ~255u;
+  // four solve blocks + two pack blocks per compute unit: the form only pays when six workgroups fit
+  if ((uint64_t)need * 6u > kMaxLds) return CAVE_E_INVALID;
+  lds = (int32_t)need;
+  return CAVE_OK;
+}
+
+int32_t cave_hip_step_lds_bytes(int64_t m_max, int64_t d) {
+  int32_t cap = 0, lds = 0;
+  const int32_t rc = step_limits(m_max, d, cap, lds);
+  return rc == CAVE_OK ? lds : rc;
+}
+
+static bool lite_store_ok(const cave_lite_store* s, int64_t need, int64_t d) {
+  return s && s->n >= need && s->d == d && s->hdr && s->usign && s->avg && s->rowptr && s->ell && s->csr16 && s->rl &&
+         (((uintptr_t)s->ell | (uintptr_t)s->csr16) & 15u) == 0 && ((4 * d) & 3) == 0;
+}
+
+int32_t cave_hip_cone_step(const cave_lite_store* solve, const float* pred, int64_t B, int32_t mode, float sign,
+                           float inner_ratio, int32_t max_iter, float* proj, float* rnorm, float* target, float* loss,
+                           float* grad, int32_t* status, int32_t* iters, const float* next_ctrs, int64_t B_next,
+                           int64_t m_max, int64_t d, const cave_lite_store* next, int32_t* pack_status,
+                           uint32_t* cu_tickets, void* stream) {
+  if (B < 0 || B_next < 0 || B + B_next >= (int64_t)1 << 31) return fail(CAVE_E_INVALID, "cone_step: bad batch sizes");
+  if (B == 0 && B_next == 0) return CAVE_OK;
+  if (d <= 0 || d > kLiteMaxD) return fail(CAVE_E_INVALID, "cone_step: need 0 < d <= 256");
+  if (!cu_tickets) return fail(CAVE_E_INVALID, "cone_step: cu_tickets is null");
+  StepParams P;
+  memset(&P, 0, sizeof(P));
+  if (B > 0) {
+    if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_step: bad mode (PROJECT .. AVG)");
+    if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_step: pred is null");
+    if (!lite_store_ok(solve, B, d)) return fail(CAVE_E_INVALID, "cone_step: bad solve store (size, d, null or unaligned array)");
+    P.S.store = *solve; P.S.pred = pred; P.S.B = B; P.S.mode = mode; P.S.sign = sign; P.S.inner_ratio = inner_ratio;
+    P.S.max_iter = max_iter > 0 ? max_iter : 100;
+    P.S.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
+  }
+  int32_t cap = 0, lds = 0;
+  if (step_limits(B_next > 0 ? m_max : 0, d, cap, lds) != CAVE_OK)
+    return fail(CAVE_E_INVALID, "cone_step: shape does not qualify (cave_hip_step_lds_bytes)");
+  if (B_next > 0) {
+    if (m_max <= 0 || m_max * d >= (int64_t)1 << 32) return fail(CAVE_E_INVALID, "cone_step: bad m_max");
+    if (!next_ctrs) return fail(CAVE_E_INVALID, "cone_step: next_ctrs is null");
+    if (!lite_store_ok(next, B_next, d)) return fail(CAVE_E_INVALID, "cone_step: bad next store (size, d, null or unaligned array)");
+    if (B > 0 && next->hdr == solve->hdr) return fail(CAVE_E_INVALID, "cone_step: solve and next must be different stores");
+    P.Q.ctrs = next_ctrs; P.Q.B = B_next; P.Q.m = (int32_t)m_max; P.Q.d = (int32_t)d; P.Q.nnz_cap = (uint32_t)cap;
+    P.Q.store = *next; P.Q.status = pack_status;
+  }
+  P.lds_bytes = (uint32_t)lds;
+  P.tickets = cu_tickets;
+  hipError_t e = launch_step((unsigned)(B + B_next), (uint32_t)lds, (hipStream_t)stream, P);
+  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch cone_step_kernel", e);
+  return CAVE_OK;
+}
+
 }  // extern "C"

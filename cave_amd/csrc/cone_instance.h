@@ -77,14 +77,16 @@ CAVE_HD void fill_failure(C& c, int d, int64_t b, const OutPtrs& o) {
 
 // scan the dense block + build the reduced cone; returns status
 // (LARGE: the arena is global memory -> predicated scan stores, no dump slots)
-template <class C, bool LARGE = false>
+// DEEP (multi-wave contexts with the 256-register budget: the step kernel's pack half): BlockCtx::scan_dense_sparse,
+// predicated stores -- no dump slots behind the scan output
+template <class C, bool LARGE = false, bool DEEP = false>
 CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, int m, int d, uint32_t cap) {
   cb.d = d;
   cb.m = m;
   // (row << 16) | col packing of the scan output, 32-bit flat index
   if (m > 0xffff || d > 0xffff || (uint64_t)m * (uint64_t)d > 0xffffffffull) return ST_TOO_LARGE;
   // scan output = build-phase temporaries at the top of the arena (+ per-thread dump slots)
-  const uint32_t dump_slots = LARGE ? 0u : (uint32_t)C::NT;
+  const uint32_t dump_slots = (LARGE || DEEP) ? 0u : (uint32_t)C::NT;
   cb.erc = ar.get_top<uint32_t>(cap + dump_slots);
   cb.eall = ar.get_top<float>(cap + dump_slots);
   cb.rptr = ar.get_top<uint32_t>((uint32_t)m + 1u);
@@ -92,7 +94,9 @@ CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, i
   for (int r = c.tid(); r <= m; r += C::NT) cb.rptr[r] = 0u;
   c.sync();
   CAVE_T0();
-  uint32_t nnz = c.template scan_dense<LARGE>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);  // erc = flat index for now
+  uint32_t nnz;  // (erc = flat index for now)
+  if constexpr (DEEP) nnz = c.template scan_dense_sparse<16>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);
+  else nnz = c.template scan_dense<LARGE>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);
   c.sync();
   CAVE_ACC(10);
   if (nnz > cap) return ST_TOO_LARGE;

@@ -228,10 +228,11 @@ struct BlockCtx {
   // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns
   // the U consecutive 1 KiB chunks [w*U, (w+1)*U) of a NW*U KiB window, so flat order is
   // wave-major; one barrier per round turns the per-wave non-zero counts into slot bases.
-  template <bool COND = false>
+  // U: KiB per wave per batch (two batches in flight)
+  template <bool COND = false, int U = SCAN_UNROLL>
   __device__ __forceinline__ uint32_t scan_dense(const float* __restrict__ A, uint32_t n, uint32_t* eflat, float* eval,
                                                  uint32_t cap) {
-    constexpr int U = SCAN_UNROLL;
+    static_assert(U <= 16, "component masks of a batch are packed into 64 bits");
     uint32_t cursor = 0;
     const uint32_t dump = cap + (uint32_t)t;
     uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)A & 15u)) & 15u) >> 2);
@@ -251,7 +252,8 @@ struct BlockCtx {
       }
     };
     auto scan_batch = [&](const float4* buf, uint32_t r0) {
-      uint32_t rel[U], nzm = 0, wsum = 0, nonempty = 0;
+      uint32_t rel[U], wsum = 0;
+      uint64_t nzm = 0, cmv = 0;  // 4 bits per chunk: this lane's component mask / the wave's (uniform)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint32_t i = r0 + woff + (uint32_t)u * 64u;
@@ -259,9 +261,9 @@ struct BlockCtx {
         if (i >= n4) v = z4;
         ChunkSlots s = chunk_slots(v);
         rel[u] = wsum + s.rel;
-        nzm |= s.nzm << (4 * u);
+        nzm |= (uint64_t)s.nzm << (4 * u);
         wsum += s.total;
-        nonempty |= (s.total != 0u ? 1u : 0u) << u;  // wave-uniform
+        cmv |= (uint64_t)s.cm << (4 * u);
       }
       uint32_t pre, tot;
       wave_prefix(wsum, pre, tot);
@@ -269,10 +271,113 @@ struct BlockCtx {
         const uint32_t base = cursor + pre;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (!((nonempty >> u) & 1u)) continue;  // this wave's chunk u holds no non-zero at all
+          const uint32_t cm = (uint32_t)(cmv >> (4 * u)) & 15u;
+          if (cm == 0u) continue;  // this wave's chunk u holds no non-zero at all
           uint32_t i = r0 + woff + (uint32_t)u * 64u;
-          if constexpr (COND) chunk_emit_cond(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, eflat, eval, cap);
-          else chunk_emit(buf[u], head + 4u * i, base, rel[u], (nzm >> (4 * u)) & 15u, dump, eflat, eval, cap);
+          const uint32_t nz4 = (uint32_t)(nzm >> (4 * u)) & 15u;
+          if constexpr (COND) chunk_emit_cond(buf[u], head + 4u * i, base, rel[u], nz4, eflat, eval, cap);
+          else chunk_emit(buf[u], head + 4u * i, base, rel[u], nz4, dump, eflat, eval, cap);
+        }
+      }
+      cursor += tot;
+    };
+    if (n4 > 0) load_batch(bufA, 0);
+    for (uint32_t r0 = 0; r0 < n4; r0 += 2u * round) {
+      if (r0 + round < n4) load_batch(bufB, r0 + round);
+      scan_batch(bufA, r0);
+      if (r0 + round < n4) {
+        if (r0 + 2u * round < n4) load_batch(bufA, r0 + 2u * round);
+        scan_batch(bufB, r0 + round);
+      }
+    }
+    const uint32_t done = head + 4u * n4;
+    if (done < n) scan_single(A, done, n, cursor, eflat, eval, cap);
+    return cursor;
+  }
+  // The scan of the step kernel's pack half (256-register budget), same contract and output order as scan_dense but
+  // PREDICATED stores (no dump slots: eflat / eval hold `cap` entries), for SPARSE cones -- what this domain has: a
+  // TSP-20 instance holds ~1 100 non-zeros in 44 080 elements, one or two per KiB.  scan_dense runs ~100 instructions
+  // per KiB chunk whatever it holds; here a chunk costs ~8 when it is empty (one OR-test + ballot), ~45 when no lane
+  // holds more than one non-zero (ONE ballot + mbcnt gives the slots; the lanes with a non-zero store it under their
+  // exec mask), the full four-ballot form only when some lane's float4 holds two or more (runs of consecutive edges
+  // in TSP degree / cut rows).  U = 16: 32 KiB in flight per wave (a lone workgroup per compute unit is bound by
+  // memory latency, ~5 k cycles per round trip: tools/micro/stream_wg.hip).
+  // Tried and dropped (round 4, same pack-only timing within 5 %: the pack is bound by waits, not by this loop's
+  // instruction count -- SQ_WAIT_ANY 52 %, SQ_WAIT_INST_ANY 20 % of its wave cycles): dword loads with one element
+  // per lane and the whole share of a wave resident in registers (one ballot per 64 floats, one barrier per round).
+  template <int U>
+  __device__ __forceinline__ uint32_t scan_dense_sparse(const float* __restrict__ A, uint32_t n, uint32_t* eflat, float* eval,
+                                                        uint32_t cap) {
+    static_assert(U <= 16, "component masks of a batch are packed into 64 bits");
+    uint32_t cursor = 0;
+    uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)A & 15u)) & 15u) >> 2);
+    if (head > n) head = n;
+    if (head) scan_single(A, 0u, head, cursor, eflat, eval, cap);
+    const float4* __restrict__ A4 = reinterpret_cast<const float4*>(A + head);
+    const uint32_t n4 = (n - head) >> 2;
+    const uint32_t round = 64u * U * NW;
+    const uint32_t woff = (uint32_t)wave * 64u * U + (uint32_t)lane;
+    float4 bufA[U], bufB[U];
+    auto load_batch = [&](float4* buf, uint32_t r0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t i = r0 + woff + (uint32_t)u * 64u;
+        buf[u] = CAVE_NT_LOAD_F4(&A4[i < n4 ? i : n4 - 1u]);  // unconditional dwordx4 from a clamped index; read once: nt
+      }
+    };
+    auto scan_batch = [&](const float4* buf, uint32_t r0) {
+      uint32_t rel[U], wsum = 0;
+      uint64_t nzm = 0;            // 4 bits per chunk: this lane's component mask
+      uint32_t anym = 0, multim = 0;  // wave-uniform, one bit per chunk: not empty / some lane holds two or more
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = r0 + woff + (uint32_t)u * 64u;
+        const float4 v = buf[u];
+        // any non-zero in this lane's float4?  (+-0 have no bits below the sign; NaN counts, as `x != 0.0f` does)
+        const uint32_t bits = (f2u(v.x) | f2u(v.y) | f2u(v.z) | f2u(v.w)) & 0x7fffffffu;
+        const bool mine = bits != 0u && i < n4;
+        const uint64_t any = __ballot(mine);
+        rel[u] = wsum;
+        if (any == 0ull) continue;  // wave-uniform: the chunk is empty
+        anym |= 1u << u;
+        const uint32_t n0 = mine && v.x != 0.0f, n1 = mine && v.y != 0.0f, n2 = mine && v.z != 0.0f, n3 = mine && v.w != 0.0f;
+        const uint32_t m4 = n0 | (n1 << 1) | (n2 << 2) | (n3 << 3);
+        nzm |= (uint64_t)m4 << (4 * u);
+        const uint64_t multi = __ballot((m4 & (m4 - 1u)) != 0u);
+        if (multi == 0ull) {  // wave-uniform: one non-zero per lane at most
+          rel[u] += mbcnt64(any);
+          wsum += (uint32_t)__popcll(any);
+        } else {
+          multim |= 1u << u;
+          const uint64_t m0 = __ballot(n0 != 0u), m1 = __ballot(n1 != 0u), m2 = __ballot(n2 != 0u), m3 = __ballot(n3 != 0u);
+          rel[u] += mbcnt64(m0) + mbcnt64(m1) + mbcnt64(m2) + mbcnt64(m3);
+          wsum += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+        }
+      }
+      uint32_t pre, tot;
+      wave_prefix(wsum, pre, tot);
+      if (tot != 0u) {  // workgroup-uniform
+        const uint32_t base = cursor + pre;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!((anym >> u) & 1u)) continue;  // wave-uniform
+          const uint32_t i = r0 + woff + (uint32_t)u * 64u;
+          const uint32_t m4 = (uint32_t)(nzm >> (4 * u)) & 15u;
+          const uint32_t f = head + 4u * i, p0 = base + rel[u];
+          const float4 v = buf[u];
+          if (!((multim >> u) & 1u)) {
+            if (m4 != 0u && p0 < cap) {  // the lanes holding the chunk's non-zeros (one each)
+              const uint32_t comp = (uint32_t)__builtin_ctz(m4);
+              eflat[p0] = f + comp;
+              eval[p0] = (m4 & 1u) ? v.x : (m4 & 2u) ? v.y : (m4 & 4u) ? v.z : v.w;
+            }
+          } else {
+            const uint32_t p1 = p0 + (m4 & 1u), p2 = p1 + ((m4 >> 1) & 1u), p3 = p2 + ((m4 >> 2) & 1u);
+            if ((m4 & 1u) && p0 < cap) { eflat[p0] = f; eval[p0] = v.x; }
+            if ((m4 & 2u) && p1 < cap) { eflat[p1] = f + 1u; eval[p1] = v.y; }
+            if ((m4 & 4u) && p2 < cap) { eflat[p2] = f + 2u; eval[p2] = v.z; }
+            if ((m4 & 8u) && p3 < cap) { eflat[p3] = f + 3u; eval[p3] = v.w; }
+          }
         }
       }
       cursor += tot;

@@ -23,6 +23,7 @@
 #include "ctx_wave.h"
 #include "ctx_block.h"
 #include "cone_instance.h"
+#include "cone_step.h"
 
 namespace cave {
 
@@ -156,6 +157,93 @@ __global__ __launch_bounds__(C::NT, MINB) void cone_packed_large_kernel(PackedPa
   }
 }
 
+// ---- fused step kernel (cone_step.h): blocks [0, S.B) solve the current batch from its lite store, one wave each;
+// blocks [S.B, S.B + Q.B) pack the next dense batch, CP::NWAVES waves each.  ONE workgroup shape (CP::NT threads, 256
+// VGPRs: the solver's budget) and one LDS size for both halves.
+//
+// Why TWO-wave workgroups.  A compute unit holds eight 256-register waves, two per SIMD.  Four of them are the solve
+// waves of its four solve blocks; the pack workgroups get the other four -- and a workgroup is only dispatched when
+// ALL its waves find a slot.  With four-wave pack workgroups a second one could not start before the LAST solve wave
+// of the compute unit had ended: the pack ran strictly one workgroup (~40 us) at a time per compute unit and trailed
+// the solve by 35 us (150 us per step).  Two-wave workgroups go two at a time from the start, a third as soon as two
+// solve waves are done (tools/micro/placement.hip, stand-in waves: 120 us for 110 us of solve).
+//
+// Wave election of a solve block.  All but one of its waves exit at once; the one that stays must not share its SIMD
+// with the staying wave of another solve block of the same compute unit (two 256-register waves fill a SIMD: pack
+// waves could not be placed there, and the two solves would halve each other's issue rate -- "wave 0 stays" leaves 6 %
+// of the SIMDs with two solve waves and the stand-in launch takes 171 us instead of 120).  So a solve block CLAIMS a
+// SIMD of its compute unit (HW_REG_HW_ID / XCC_ID) in a per-compute-unit bit mask in global memory: the SIMD of its
+// wave 0 if free, else that of wave 1, ...; the wave sitting on the claimed SIMD stays and releases the bit when it
+// ends.  (Measured: 1024 solve waves on 1024 different SIMDs, no failed claim.)
+template <int NW>
+__device__ __forceinline__ int step_elect_wave(unsigned char* smem, uint32_t* masks, uint32_t& claim) {
+  uint32_t* sh = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID [3:0]
+  const uint32_t cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+  if ((threadIdx.x & 63u) == 0u) sh[4 + (threadIdx.x >> 6)] = (hw >> 4) & 3u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t sel = 0, bit = 0;
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t sb = 1u << sh[4 + w];
+      const uint32_t old = atomicOr(&masks[cu], sb);
+      if (!(old & sb)) { sel = (uint32_t)w; bit = sb; break; }
+    }
+    sh[0] = sel;   // (no claim succeeded: wave 0 stays without one)
+    sh[1] = bit;
+    sh[2] = cu;
+  }
+  __syncthreads();
+  claim = sh[1] ? ((sh[2] << 4) | sh[1]) : 0u;
+  return (int)sh[0];
+}
+__device__ __forceinline__ void step_release(uint32_t* masks, uint32_t claim) {
+  if (claim) atomicAnd(&masks[claim >> 4], ~(claim & 15u));
+}
+
+template <class CP>
+__global__ __launch_bounds__(CP::NT, 2) void cone_step_kernel(StepParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int64_t b = blockIdx.x;
+  if (b < P.S.B) {
+    uint32_t claim = 0;
+    const int sel = step_elect_wave<CP::NWAVES>(smem, P.tickets, claim);
+    if ((int)(threadIdx.x >> 6) != sel) return;
+    SoloCtx<32, 4> sc;
+    sc.lane = (int)(threadIdx.x & 63u);
+#ifdef CAVE_STAMPS
+    unsigned long long stamps[32];
+    for (int i = 0; i < 32; ++i) stamps[i] = 0;
+    sc.st = stamps;
+    unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    run_lite_instance(sc, smem + kStepElectBytes, P.lds_bytes - kStepElectBytes, P.S, b);
+    if (sc.lane == 0) step_release(P.tickets, claim);
+#ifdef CAVE_STAMPS
+    stamps[14] = __builtin_amdgcn_s_memtime() - mt0;
+    stamps[15] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz
+    stamps[0] = rt0;
+    if (sc.lane == 0 && b < 4096) for (int i = 0; i < 16; ++i) g_stamp_buf[b * 16 + i] = stamps[i];
+#endif
+    return;
+  }
+  CP c;
+  c.init(smem);
+  const int64_t q = b - P.S.B;
+#ifdef CAVE_STAMPS
+  for (int i = 0; i < 32; ++i) c.st[i] = 0;
+  unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if (q < P.Q.B) run_pack_lite_instance(c, smem, P.lds_bytes, P.Q, q);
+#ifdef CAVE_STAMPS
+  c.st[14] = __builtin_amdgcn_s_memtime() - mt0;
+  c.st[15] = rt0;
+  c.st[9] = __builtin_amdgcn_s_memrealtime();
+  if (c.tid() == 0 && q < 4096 && q < P.Q.B) for (int i = 0; i < 16; ++i) g_stamp_buf[(4096 + q) * 16 + i] = c.st[i];
+#endif
+}
+
 // ---------------------------------------------------------------- launch table (host)
 // One function per kernel shape, defined next to its instantiation (k_*.hip).  Each sets the dynamic-LDS
 // attribute when the launch needs more than 48 KiB, launches on `stream` and returns hipGetLastError().
@@ -180,6 +268,7 @@ CAVE_DECL_LAUNCH_LARGE(launch_pack_large, PackParams);
 CAVE_DECL_LAUNCH_LARGE(launch_packed_large_w1, PackedParams);
 CAVE_DECL_LAUNCH_LARGE(launch_packed_large_w2, PackedParams);
 CAVE_DECL_LAUNCH_LARGE(launch_packed_large_w4, PackedParams);
+CAVE_DECL_LAUNCH(launch_step, StepParams);
 
 template <class K>
 static inline hipError_t ensure_lds(K kernel, uint32_t bytes) {

@@ -336,6 +336,7 @@ struct ChunkSlots {
   uint32_t rel;    // slot of this lane's first non-zero, relative to the chunk start
   uint32_t nzm;    // 4-bit component mask
   uint32_t total;  // wave-uniform
+  uint32_t cm;     // wave-uniform: bit c set when ANY lane's component c is non-zero
 };
 __device__ __forceinline__ ChunkSlots chunk_slots(float4 v) {
   bool n0 = v.x != 0.0f, n1 = v.y != 0.0f, n2 = v.z != 0.0f, n3 = v.w != 0.0f;
@@ -344,6 +345,7 @@ __device__ __forceinline__ ChunkSlots chunk_slots(float4 v) {
   s.rel = mbcnt64(m0) + mbcnt64(m1) + mbcnt64(m2) + mbcnt64(m3);
   s.nzm = (uint32_t)n0 | ((uint32_t)n1 << 1) | ((uint32_t)n2 << 2) | ((uint32_t)n3 << 3);
   s.total = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+  s.cm = (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
   return s;
 }
 // Branch-free store of a chunk's non-zeros at slots base+rel...; zero components (and slots beyond

@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from .qpsolver import _grow_limits, _large_guess, _raise_for_status, fast_path_cannot_fit
 
-__all__ = ["ConeStore", "PackedBatch", "collate_ids"]
+__all__ = ["ConeStore", "PackedBatch", "collate_ids", "prefetch"]
 
 
 class ConeStore:
@@ -346,3 +346,49 @@ def collate_ids(batch):
     x, c, w, z, ids = zip(*batch)
     return (torch.stack(x, 0), torch.stack(c, 0), torch.stack(w, 0), torch.stack(z, 0),
             torch.as_tensor(ids, dtype=torch.int64))
+
+
+def prefetch(loader, slot: int = -1, device=None):
+    """Wrap a DataLoader whose batches carry the dense `tight_ctrs` in field `slot` (the reference's collate_fn puts
+    it last: src/dataset.py:133-144) so that the loop body of code_sample.py:48-60 stays as it is,
+
+        for data in prefetch(loader):
+            x, c, w, z, bctr = data
+            x, c, w, z, bctr = x.cuda(), c.cuda(), w.cuda(), z.cuda(), bctr.cuda()
+            loss = cave(reg(x), bctr); ...
+
+    and gets the fused step: `bctr` is a PreparedCones whose reduced cones are already on the device, and the loss call
+    of batch i packs batch i+1 in the same launch (qpsolver.cone_op_prepared).  One batch of look-ahead: the generator
+    pulls batch i+1 from the loader before it yields batch i.  Cones are moved to `device` (default: the current HIP
+    device) here; shapes the fused form does not take pass through as tensors."""
+    from .qpsolver import PreparedCones, prepare_dense
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def cones_of(batch):
+        return batch[slot].to(dev, non_blocking=True)
+
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    cur_cones = prepare_dense(cones_of(cur))
+    while True:
+        try:
+            nxt = next(it)
+        except StopIteration:
+            nxt = None
+        nxt_dense = cones_of(nxt) if nxt is not None else None
+        if isinstance(cur_cones, PreparedCones) and nxt_dense is not None:
+            cur_cones.then(nxt_dense)
+        out = list(cur)
+        out[slot] = cur_cones
+        yield type(cur)(out) if isinstance(cur, (tuple, list)) else out
+        if nxt is None:
+            return
+        if isinstance(cur_cones, PreparedCones) and cur_cones.next is not None:
+            nxt_cones = cur_cones.next          # packed by the loss call of the batch just yielded
+        else:                                   # (no loss call happened on it, or the shape does not qualify)
+            nxt_cones = prepare_dense(nxt_dense)
+        cur, cur_cones = nxt, nxt_cones

@@ -23,7 +23,7 @@ from ._lib import (MODE_AVG, MODE_EXACT, MODE_HEURISTIC, MODE_INNER, MODE_PROJEC
                    ST_NOT_CONVERGED, ST_OK, ST_TOO_LARGE)
 
 __all__ = ["project_hip", "average_ctrs_hip", "cone_op_dense", "HipSolverError", "PreparedCones", "prepare_dense",
-           "cone_op_prepared", "stream_mark"]
+           "cone_op_prepared", "step_lds_bytes"]
 
 
 class HipSolverError(RuntimeError):
@@ -80,6 +80,7 @@ def forget_shape(m: int, d: int) -> None:
     _wide_ok.pop(key, None)
     _large_hint.pop(key, None)
     _split_ok.pop(key, None)
+    _step_ok.pop(key, None)
     _settled.discard(key)
 
 
@@ -151,111 +152,164 @@ def _slot_store(dev, B: int, d: int) -> _SlotStore:
     return st
 
 
-# ---- prepared form: the two stages of the split form, decoupled.
+# ---- prepared form: the two stages of a step on the dense format, decoupled and then FUSED ACROSS STEPS.
 # The pack stage (stream the dense block, build the reduced cone) depends on the cones only, not on the prediction,
 # and a training loop knows the cones of the NEXT batch before it has the next prediction (the DataLoader has
-# already collated it).  `prepare_dense(next_ctrs)` runs that stage on a side stream while the current step's
-# solve kernel -- one wave per SIMD, HBM idle -- is still running; `cone_op_prepared(prepared, pred, ...)` then only
-# launches the solve.  Steady state per step = max(pack, solve) instead of their sum (TSP-20, B = 1024: 188 -> ~135 us).
-_side_streams: dict = {}
-_prep_pool: dict = {}
+# already collated it: src/dataset.py:133-144).  `prepare_dense(ctrs)` runs the pack stage of a batch into a transient
+# "lite store"; `prep.then(next_ctrs)` attaches the following batch, and `cone_op_prepared(prep, pred, ...)` then
+# launches ONE grid (cave_hip_cone_step): the one-wave solve blocks of this batch first, the four-wave pack blocks of
+# the next batch behind them, filling what the solve waves leave of each compute unit.  Steady state per step =
+# max(pack, solve) instead of their sum, on one stream: no side stream, no event, no spacer kernel (rounds 2-3 ran the
+# pack on a side stream behind a tuned `torch.cuda._sleep`, which decided a dispatch race and depended on how the
+# runtime maps streams to hardware queues).  `cave_amd.dataset.prefetch(loader)` does the wiring for a DataLoader.
+STEP_MAX_B = 2048   # the one-wave solver is a latency design: beyond ~2 instances per SIMD the general path wins
+STEP_POOL = 3       # lite stores cycled per (device, stream, B, d); two are in use by a running chain
+_step_pool: dict = {}
+_step_lds: dict = {}
+_step_ok: dict[tuple[int, int], bool] = {}  # (m, d) -> a checked batch of this shape had a cone the lite form does not take
+_tickets: dict = {}
+
+
+class _LiteSlots:
+    """B slots of a cave_lite_store (include/cave_hip.h) + the pack status of the batch it holds."""
+
+    def __init__(self, dev, B: int, d: int):
+        import ctypes as C
+
+        self.B, self.d = B, d
+        t = {
+            "hdr": torch.zeros(B * 8, dtype=torch.int32, device=dev),
+            "usign": torch.zeros(B * d, dtype=torch.uint8, device=dev),
+            "avg": torch.zeros(B * d, dtype=torch.float32, device=dev),
+            "rowptr": torch.zeros(B * 33, dtype=torch.int32, device=dev),
+            "ell": torch.zeros(B * 4 * d, dtype=torch.int32, device=dev),
+            "csr16": torch.zeros(B * 768, dtype=torch.int32, device=dev),
+            "rl": torch.zeros(B * 32, dtype=torch.uint8, device=dev),
+        }
+        self.t = t
+        self.c = _lib.LiteStore(n=B, d=d, reserved=0, **{k: v.data_ptr() for k, v in t.items()})
+        self.ref = C.byref(self.c)
+        self.pack_status = torch.empty(B, dtype=torch.int32, device=dev)
+        self.gen = 0  # bumped every time the store is handed out (PreparedCones.stale)
+
+
+def _tickets_for(dev) -> torch.Tensor:
+    t = _tickets.get(dev)
+    if t is None:
+        t = _tickets[dev] = torch.zeros(4096, dtype=torch.int32, device=dev)
+    return t
+
+
+def step_lds_bytes(m: int, d: int) -> int:
+    """LDS per workgroup of the fused step kernel for dense batches of shape (m_max, d); <= 0: does not qualify."""
+    key = (int(m), int(d))
+    v = _step_lds.get(key)
+    if v is None:
+        v = _step_lds[key] = int(_lib.load_library().cave_hip_step_lds_bytes(key[0], key[1]))
+    return v
+
+
+def _take_store(dev, B: int, d: int, avoid=None) -> _LiteSlots:
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, B, d)
+    pool = _step_pool.get(key)
+    if pool is None:
+        if len(_step_pool) >= 8:
+            _step_pool.pop(next(iter(_step_pool)))
+        pool = _step_pool[key] = []
+    if len(pool) < STEP_POOL:
+        ss = _LiteSlots(dev, B, d)
+    else:
+        ss = pool.pop(0)  # round robin: the store handed out STEP_POOL calls ago (its holder is stale from now on)
+        if ss is avoid:
+            pool.append(ss)
+            ss = pool.pop(0)
+    pool.append(ss)
+    ss.gen += 1
+    return ss
 
 
 class PreparedCones:
-    """A dense (B, m_max, d) batch whose reduced cones sit in a transient slot store (or are being put there on
-    the side stream).  Usable once in place of `tight_ctrs` in a loss call; keeps the dense tensor alive for the
-    fallback of a batch that does not fit the slots -- or whose slot store has been handed to a later prepare()
-    in the meantime (`gen` no longer matches the store's: more prepared batches held than the pool has stores)."""
+    """A dense (B, m_max, d) batch whose reduced cones sit in a transient lite store (packed by an earlier launch on
+    the same stream).  Usable in place of `tight_ctrs` in a loss call.  `then(next_ctrs)` attaches the batch that
+    follows: the loss call then packs it in the same launch and leaves its PreparedCones in `.next`.  Keeps the dense
+    tensor alive for the fallback of a batch the lite form does not take -- or whose store has been handed out again
+    in the meantime (`gen` no longer matches: more prepared batches held than the pool has stores)."""
 
-    def __init__(self, ctrs: torch.Tensor, store, event, gen: int):
-        self.ctrs, self.store, self.event, self.gen = ctrs, store, event, gen
+    def __init__(self, ctrs: torch.Tensor, store: _LiteSlots, gen: int):
+        self.ctrs, self.store, self.gen = ctrs, store, gen
         self.shape = tuple(ctrs.shape)
+        self.follow = None   # dense tensor of the batch after this one (consumed by the first solve)
+        self.next = None     # what to pass for that batch: a PreparedCones, or the tensor itself
 
     def stale(self) -> bool:
         return self.gen != self.store.gen
 
+    def then(self, next_ctrs: "torch.Tensor | None") -> "PreparedCones":
+        self.follow, self.next = next_ctrs, None
+        return self
 
-PREP_POOL = 3  # slot stores cycled by prepare_dense per (device, B, d): a DataLoader prefetch depth of up to 3
+    # a training loop moves every field of a batch to the device (code_sample.py:50): nothing to move here
+    def cuda(self, *a, **k) -> "PreparedCones":
+        return self
 
+    def to(self, *a, **k) -> "PreparedCones":
+        return self
 
-def stream_mark(device=None) -> "torch.cuda.Event":
-    """An event recorded on the current stream now: pass it as `ready=` to a prepare() call issued LATER in host
-    order (after the solve of the running step has been enqueued), so that the pack waits for what preceded the
-    mark only and overlaps with that solve."""
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    return ev
-
-
-PIPE_PACK_WAVES = 4  # wave shape of the pack kernel on the side stream (1 / 2 / 4 / 8)
-# Cycles (torch.cuda._sleep) a one-workgroup spin kernel holds the side stream back behind `ready` (0 = off; ~10 us).  The pack and the solve it is to
-# overlap with become runnable at the same moment; whichever kernel is dispatched first takes the residency of the
-# machine (both fill it: 4 workgroups per CU), and the other one then runs AFTER it instead of beside it.  The spacer
-# lets the solve -- one or two queue packets behind the mark -- go first; the pack then fills what the solve leaves.
-PIPE_SPACER_CYCLES = 25000
+    @property
+    def device(self):
+        return self.ctrs.device
 
 
-def prepare_dense(tight_ctrs: torch.Tensor, ready: "torch.cuda.Event | None" = None) -> "PreparedCones | torch.Tensor":
-    """Start the pack stage for a dense batch on the side stream.  Returns the tensor itself when the shape does
-    not qualify for the split form (the loss call then takes the ordinary path).
-    `ready`: event after which the dense tensor is valid (default: everything enqueued on the current stream so
-    far).  To overlap with the solve of the running step, enqueue that solve FIRST (its workgroups then take their
-    residency first) and pass a `stream_mark()` taken before it."""
+def _step_qualifies(t) -> bool:
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 3):
+        return False
+    B, m, d = t.shape
+    return 0 < m and d <= SPLIT_MAX_D and 0 < B <= STEP_MAX_B and _step_ok.get((m, d)) is not False and step_lds_bytes(m, d) > 0
+
+
+def _launch_step(solve, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, nxt_ctrs, nxt_store):
     lib = _lib.load()
-    B, m, d = tight_ctrs.shape
-    if not (tight_ctrs.is_cuda and 0 < m and d <= SPLIT_MAX_D and 0 < B <= 2048) or _split_ok.get((m, d)) is False:
+    Bn, mn, dn = (nxt_ctrs.shape if nxt_ctrs is not None else (0, 0, solve.d))
+    dev = pred.device if pred is not None else nxt_ctrs.device
+    rc = lib.cave_hip_cone_step(
+        solve.ref if solve is not None else None, _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio), int(max_iter),
+        _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")), _lib.ptr(out.get("loss")),
+        _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
+        _lib.ptr(nxt_ctrs), Bn, mn, dn, nxt_store.ref if nxt_store is not None else None,
+        _lib.ptr(nxt_store.pack_status) if nxt_store is not None else None, _lib.ptr(_tickets_for(dev)), _lib.current_stream())
+    _lib.check(rc, "cave_hip_cone_step")
+
+
+def prepare_dense(tight_ctrs: torch.Tensor) -> "PreparedCones | torch.Tensor":
+    """Run the pack stage of a dense batch now, on the current stream (a pack-only launch of the step kernel).
+    Returns the tensor itself when the shape does not qualify (the loss call then takes the ordinary path)."""
+    _lib.load()
+    if not _step_qualifies(tight_ctrs):
         return tight_ctrs
     dev = tight_ctrs.device
     ctrs = _as_device(tight_ctrs, dev)
-    # Work this call itself enqueues on the CURRENT stream -- a dtype / layout conversion of the cones, the fills
-    # that initialise a new slot store -- is not covered by the caller's earlier mark: the side stream must wait
-    # for it too, or the pack would read unconverted cones / have its output zeroed afterwards (ADVICE r2).
-    fresh_work = ctrs.data_ptr() != tight_ctrs.data_ptr()
-    pool = _prep_pool.setdefault((dev, B, d), [])
-    if len(pool) < PREP_POOL:
-        ss = _SlotStore(dev, B, d)
-        fresh_work = True
-    else:
-        ss = pool.pop(0)  # round robin: the store handed out PREP_POOL calls ago (its holder is stale from now on)
-    pool.append(ss)
-    ss.gen += 1
-    side = _side_streams.get(dev)
-    if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    # the dense tensor must be ready; a recycled slot store was last read by a solve launched PREP_POOL prepare()
-    # calls ago on the current stream, which an event of "now" (or the caller's earlier mark) covers too
-    if ready is None or fresh_work:
-        side.wait_event(stream_mark(dev))
-    if ready is not None:
-        side.wait_event(ready)
-    ctrs.record_stream(side)
-    with torch.cuda.stream(side):
-        if ready is not None and PIPE_SPACER_CYCLES > 0 and hasattr(torch.cuda, "_sleep"):
-            torch.cuda._sleep(PIPE_SPACER_CYCLES)  # (PyTorch's own spin kernel: one workgroup)
-        rc = lib.cave_hip_pack_fill(_lib.ptr(ctrs), B, m, d, 0, 0, PIPE_PACK_WAVES, ss.ref, 0, _lib.ptr(ss.pack_status),
-                                    C_void(side.cuda_stream))
-        _lib.check(rc, "cave_hip_pack_fill (slot mode, side stream)")
-        ev = torch.cuda.Event()
-        ev.record(side)
-    return PreparedCones(ctrs, ss, ev, ss.gen)
-
-
-def C_void(x):
-    import ctypes
-
-    return ctypes.c_void_p(x)
+    B, m, d = ctrs.shape
+    with torch.cuda.device(dev):
+        ss = _take_store(dev, B, d)
+        _launch_step(None, None, 0, MODE_PROJECT, 1.0, 0.0, 0, {}, None, None, ctrs, ss)
+    return PreparedCones(ctrs, ss, ss.gen)
 
 
 def cone_op_prepared(prep: PreparedCones, pred_cost: torch.Tensor, mode: int, sign: float = 1.0, inner_ratio: float = 0.2, *,
                      max_iter: int = 0, check: bool = True,
                      outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
-    """The solve stage for a prepared batch (same outputs as cone_op_dense).  A batch with an instance beyond the
-    slot capacity falls back to cone_op_dense on the dense tensor (checked calls only; unchecked calls report
+    """The solve stage for a prepared batch (same outputs as cone_op_dense) and, in the same launch, the pack stage of
+    the batch attached with `prep.then(...)`, whose PreparedCones is left in `prep.next`.  A batch with a cone the lite
+    form does not take falls back to cone_op_dense on the dense tensor (checked calls only; unchecked calls report
     CAVE_ST_TOO_LARGE in `status`)."""
-    lib = _lib.load()
+    _lib.load()
     B, m, d = prep.shape
     dev = prep.ctrs.device
-    if prep.stale():  # its slot store now holds a later batch: solve from the dense tensor it kept
+    follow, prep.follow = prep.follow, None
+    if prep.stale() or mode == _lib.MODE_INNER_IPM:
+        # its store now holds a later batch (or the mode is not one of the step kernel's): solve from the dense tensor
+        if follow is not None:
+            prep.next = prepare_dense(follow)
         return cone_op_dense(prep.ctrs, pred_cost, mode, sign, inner_ratio, max_iter=max_iter, check=check, outputs=outputs)
     pred = _as_device(pred_cost, dev)
     if pred.shape != (B, d):
@@ -267,16 +321,18 @@ def cone_op_prepared(prep: PreparedCones, pred_cost: torch.Tensor, mode: int, si
         status = torch.empty(B, dtype=torch.int32, device=dev)
         iters = torch.empty(B, dtype=torch.int32, device=dev)
         out["status"], out["iters"] = status, iters
-        ss = prep.store
-        torch.cuda.current_stream(dev).wait_event(prep.event)
-        rc = lib.cave_hip_cone_packed(
-            ss.ref, None, _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio), int(max_iter), ss.lds_bytes, 1,
-            _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
-            _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters), _lib.current_stream())
-        _lib.check(rc, "cave_hip_cone_packed (prepared)")
+        nctrs = nstore = None
+        if follow is not None:
+            if _step_qualifies(follow):
+                nctrs = _as_device(follow, dev)
+                nstore = _take_store(dev, int(nctrs.shape[0]), int(nctrs.shape[2]), avoid=prep.store)
+                prep.next = PreparedCones(nctrs, nstore, nstore.gen)
+            else:
+                prep.next = follow
+        _launch_step(prep.store, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, nctrs, nstore)
         if check:
             if bool((status == ST_TOO_LARGE).any()):
-                _split_ok[(m, d)] = False
+                _step_ok[(m, d)] = False
                 return cone_op_dense(prep.ctrs, pred_cost, mode, sign, inner_ratio, max_iter=max_iter, check=True,
                                      outputs=outputs)
             _raise_for_status(status, "solver='hip' (prepared)")

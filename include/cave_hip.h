@@ -22,6 +22,10 @@
  *   cave_hip_pack_*  / cave_hip_cone_packed
  *                                       optDatasetConstrs.ctrs storage + collate_fn padding
  *                                       src/dataset.py:72, 133-144 (device-resident replacement)
+ *   cave_hip_cone_step                  one training step's worth of both on the dense wire format, in ONE launch:
+ *                                       the forward / backward of the CURRENT batch (src/cave.py:55-73) from a
+ *                                       transient store + the collate-side work on the NEXT batch the DataLoader
+ *                                       has already produced (src/dataset.py:133-144)
  *   cave_hip_*_large                    the same three operators for cones whose reduced system does
  *                                       not fit registers / LDS (TSP-100, 30x30 shortest path: the
  *                                       reference runs them through the same _project_nnls,
@@ -37,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 8
+#define CAVE_HIP_ABI_VERSION 9
 
 /* return codes */
 #define CAVE_OK 0
@@ -226,6 +230,57 @@ int32_t cave_hip_cone_packed_large(const cave_cone_store* store, const int64_t* 
                                    int32_t waves, void* workspace, int64_t slice_bytes, int32_t n_slots, float* proj,
                                    float* rnorm, float* target, float* loss, float* grad, int32_t* status,
                                    int32_t* iters, void* stream);
+
+/* ------------------------------------------------------------------ fused step (v9)
+ * Small +-1 cones on the dense wire format (TSP-20, small grids: d <= 256, <= 32 reduced rows in the order
+ * [free | <= 8 bound rows], <= 8 entries per column, <= 1536 non-zeros -- what the one-wave solver takes).
+ *
+ * A step on the dense format is  (a) stream the dense block + build the reduced cone  ->  (b) Newton solve + loss +
+ * gradient.  (a) depends on the cones only, and the training loop has the cones of batch i+1 before it has the
+ * prediction of batch i+1 (the DataLoader collates ahead), so cave_hip_cone_step runs (b) of the CURRENT batch and (a)
+ * of the NEXT batch in one grid: B one-wave solve instances first in the block order, then B_next four-wave pack
+ * workgroups, which fill what the solve waves leave of each compute unit.  One stream, no events.
+ *
+ * cave_lite_store: transient per-batch store in the layout the one-wave solver reads (caller-owned device arrays):
+ *   hdr    [n*8]    int32: state (1 = holds a cone, -1 = the cone does not qualify, 0 = never packed), reduced rows p,
+ *                   non-zeros, free rows nF (rows [0, nF) have free multipliers), rows kept by the projection,
+ *                   longest column, CSR entries per lane (8 / 16 / 24), spare
+ *   usign  [n*d]    bit0: a +e_k row exists, bit1: a -e_k row exists
+ *   avg    [n*d]    _average_ctrs of the instance
+ *   rowptr [n*33]   CSR row pointers of the reduced rows
+ *   ell    [n*4*d]  uint32: the column of coordinate k as eight 16-bit entries (reduced row | sign << 15; unused: row 32)
+ *   csr16  [n*768]  uint32: CSR entries as 16-bit words (column | sign << 15 | row-end marks), lane-major groups of 8
+ *   rl     [n*32]   lane holding the last entry of reduced row i
+ * (ell / csr16 need 16-byte aligned bases.) */
+typedef struct cave_lite_store {
+  int64_t n;
+  int32_t d;
+  int32_t reserved;
+  int32_t* hdr;
+  uint8_t* usign;
+  float* avg;
+  uint32_t* rowptr;
+  uint32_t* ell;
+  uint32_t* csr16;
+  uint8_t* rl;
+} cave_lite_store;
+
+/* dynamic LDS per workgroup of cave_hip_cone_step for dense batches of shape (m_max, d); <= 0: the shape does not
+ * qualify (d > 256, or five workgroups would not fit a compute unit: use the general operators) */
+int32_t cave_hip_step_lds_bytes(int64_t m_max, int64_t d);
+
+/* Solve half: instances [0, B) of `solve` (packed by an earlier call) with predictions pred [B, d]; outputs as
+ *   cave_hip_cone_dense (modes PROJECT / EXACT / INNER / HEURISTIC / AVG; an instance whose slot holds no cone reports
+ *   CAVE_ST_TOO_LARGE).  B = 0 (solve may be NULL): pack only.
+ * Pack half: instances [0, B_next) of next_ctrs [B_next, m_max, d] into slots [0, B_next) of `next` (a different
+ *   store than `solve`); pack_status [B_next] or NULL.  B_next = 0 (next_ctrs / next may be NULL): solve only.
+ * cu_tickets: 4096 uint32 of device memory, zeroed once by the caller, shared by the launches of one device (per
+ *   compute-unit counters that spread the solve waves over the SIMDs; the library keeps no state of its own). */
+int32_t cave_hip_cone_step(const cave_lite_store* solve, const float* pred, int64_t B, int32_t mode, float sign,
+                           float inner_ratio, int32_t max_iter, float* proj, float* rnorm, float* target, float* loss,
+                           float* grad, int32_t* status, int32_t* iters, const float* next_ctrs, int64_t B_next,
+                           int64_t m_max, int64_t d, const cave_lite_store* next, int32_t* pack_status,
+                           uint32_t* cu_tickets, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cave_hip_version() == 8
+    assert lib.cave_hip_version() == 9
     assert lib.cave_hip_device_count() >= 0
     assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
 
@@ -61,6 +61,16 @@ def test_default_limits_and_arg_validation():
     assert lib.cave_hip_cone_dense_large(None, None, 0, 4, 4, 0, 1.0, 0.0, 0, 64, 0, None, 0, 0, *none8) == 0  # B == 0
     assert lib.cave_hip_pack_large(None, 1, 4, 4, 64, None, 1 << 20, 4, None, None, None, 0, None, None) == -1
     assert lib.cave_hip_cone_packed_large(None, None, None, 1, 0, 1.0, 0.0, 0, 0, 0, None, 1 << 20, 4, *none8) == -1
+    # v9 fused step: six workgroups per compute unit (four solve blocks + two two-wave pack blocks) must fit the LDS at
+    # TSP-20; shapes beyond the one-wave solver are refused up front; bad arguments are rejected before any launch
+    step = lib.cave_hip_step_lds_bytes(235, 190)
+    assert 0 < step and 6 * step <= 160 * 1024
+    assert 0 < lib.cave_hip_step_lds_bytes(60, 40) <= step
+    assert lib.cave_hip_step_lds_bytes(235, 300) < 0 and lib.cave_hip_step_lds_bytes(40000, 190) < 0
+    none7 = [None] * 7
+    assert lib.cave_hip_cone_step(None, None, 0, 0, 1.0, 0.0, 0, *none7, None, 0, 0, 190, None, None, None, None) == 0  # nothing to do
+    assert lib.cave_hip_cone_step(None, None, 4, 2, 1.0, 0.2, 0, *none7, None, 0, 0, 190, None, None, None, None) == -1
+    assert b"cu_tickets" in lib.cave_hip_last_error()
 
 
 def test_status_codes_match_header():

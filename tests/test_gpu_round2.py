@@ -299,10 +299,17 @@ def test_training_harness_on_tsp_with_warm_start():
     assert all(m <= 3.0 for m, _ in log[1:]), log
 
 
-def test_prepared_form_pipelines_pack_and_solve(golden):
-    """loss_fn.prepare(next_bctr): the prediction-independent pack stage on a side stream; the later loss call only
-    launches the solve.  Same numbers as the ordinary call, also through the modules, also after many reuses of the
-    three slot stores, and a batch beyond the slot capacity falls back."""
+def _close(a, b, tol=1e-6):
+    import torch
+
+    return bool(torch.isfinite(a).all()) and float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+def test_prepared_form_fuses_pack_and_solve(golden):
+    """loss_fn.prepare(bctr) / prep.then(next_bctr): the prediction-independent pack stage of the NEXT batch rides in
+    the launch of this batch's solve (cave_hip_cone_step: one grid, solve blocks first).  Same numbers as the ordinary
+    call, also through the modules, also after many reuses of the three lite stores, and a batch with a cone the
+    one-wave solver does not take falls back."""
     import torch
 
     from cave_amd import qpsolver, synth
@@ -320,11 +327,22 @@ def test_prepared_form_pipelines_pack_and_solve(golden):
     prep = prepare_dense(batches[0][0])
     assert isinstance(prep, PreparedCones)
     for i, (c, p) in enumerate(batches):
-        nxt = prepare_dense(batches[(i + 1) % len(batches)][0])   # next batch's pack overlaps this batch's solve
+        prep.then(batches[(i + 1) % len(batches)][0])   # the next batch's pack rides in this batch's solve launch
         got = cone_op_prepared(prep, p, MODE_INNER, -1.0, 0.2, outputs=ALL)
+        assert bool((got["status"] == 0).all()) and torch.equal(got["iters"], want[i]["iters"]), i
         for k in ALL:
-            assert torch.equal(got[k], want[i][k]), (i, k)
-        prep = nxt
+            assert _close(got[k], want[i][k]), (i, k)
+        prep = prep.next
+        assert isinstance(prep, PreparedCones) and not prep.stale()
+    # every mode of the step kernel against the general operator (PROJECT / EXACT / HEURISTIC / AVG)
+    from cave_amd._lib import MODE_AVG, MODE_EXACT, MODE_HEURISTIC, MODE_PROJECT
+    c, p = batches[1]
+    for mode, outs in ((MODE_PROJECT, ("proj", "rnorm")), (MODE_EXACT, ALL), (MODE_HEURISTIC, ("target", "loss", "grad")),
+                       (MODE_AVG, ("target",))):
+        got = cone_op_prepared(prepare_dense(c), p, mode, -1.0, 0.2, outputs=outs)
+        ref = cone_op_dense(c, p, mode, -1.0, 0.2, outputs=outs)
+        for k in outs:
+            assert _close(got[k], ref[k]), (mode, k)
 
     class M:
         modelSense = EPO.MINIMIZE
@@ -332,13 +350,16 @@ def test_prepared_form_pipelines_pack_and_solve(golden):
     mod = innerConeAlignedCosine(M(), solver="hip", seed=0)
     c, p = batches[2]
     pr = p.clone().requires_grad_(True)
-    l1 = mod(pr, mod.prepare(c))
+    nxt = mod.prepare(c, batches[3][0])
+    l1 = mod(pr, nxt)
     l1.backward()
     pr2 = p.clone().requires_grad_(True)
     l2 = mod(pr2, c)
     l2.backward()
-    assert torch.equal(l1.detach(), l2.detach()) and torch.equal(pr.grad, pr2.grad)
-    # beyond the slots: a dense row block makes instance 3 a non +-1 cone with 40 general rows
+    assert _close(l1.detach(), l2.detach()) and _close(pr.grad, pr2.grad)
+    l3 = mod(batches[3][1], nxt.next)   # the batch packed beside that solve
+    assert _close(l3, mod(batches[3][1], batches[3][0]))
+    # a cone the lite form does not take: a dense row block makes instance 3 a non +-1 cone with 40 general rows
     big = ctrs[:8].copy()
     big[3, :40, :30] = rng.standard_normal((40, 30)).astype(np.float32)
     qpsolver.forget_shape(*key)

@@ -55,93 +55,102 @@ def test_warm_start_with_repeated_ids():
                 pred = pred + torch.tensor(rng.normal(0, 0.01, pred.shape).astype(np.float32), device="cuda")
 
 
-def test_prepared_form_from_the_first_step_and_beyond_the_pool():
-    """qpsolver.prepare_dense(ready=stream_mark()) from the very first step (the fills that initialise a
-    new slot store are enqueued on the current stream AFTER the mark; the side stream has to wait for them too),
-    and more prepared batches held at once than the pool has slot stores (a stale one falls back to its dense
-    tensor instead of solving another batch's cones)."""
+def test_prepared_form_chain_and_beyond_the_pool():
+    """The fused step (qpsolver.prepare_dense / PreparedCones.then / cone_op_prepared) behind other work on the stream,
+    over more batches than the pool has lite stores (each store is recycled while its predecessor's launch is still
+    in flight: one stream orders them -- ADVICE r3: the side-stream form could hand out a store a running solve was
+    reading), with more prepared batches HELD than the pool has stores (a stale one falls back to its dense tensor
+    instead of solving another batch's cones), and on float64 cones."""
     import torch
 
     from cave_amd import qpsolver, synth
-    from cave_amd.qpsolver import PREP_POOL, PreparedCones, cone_op_dense, cone_op_prepared, prepare_dense, stream_mark
+    from cave_amd.qpsolver import STEP_POOL, PreparedCones, cone_op_dense, cone_op_prepared, prepare_dense
 
     ctrs, costs, _ = synth.tsp_batch(20, 96, seed=21)
     qpsolver.forget_shape(ctrs.shape[1], ctrs.shape[2])  # whatever earlier tests concluded about this (m_max, d)
     rng = np.random.default_rng(8)
     batches = [(torch.tensor(ctrs[rng.permutation(96)[:40]], device="cuda"),
                 torch.tensor(costs[:40] + rng.normal(0, 0.1, (40, costs.shape[1])).astype(np.float32), device="cuda"))
-               for _ in range(PREP_POOL + 3)]
+               for _ in range(2 * STEP_POOL + 1)]
     want = [cone_op_dense(c, p, MODE_INNER, -1.0, 0.2, outputs=ALL) for c, p in batches]
-    qpsolver._prep_pool.clear()  # every store of this run is created inside the loop below
-    # a long-running kernel on the current stream, then a mark, then the prepare: the pack may only wait for the mark
+
+    def close(a, b):
+        return float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+    qpsolver._step_pool.clear()  # every store of this run is created inside the loop below
     big = torch.randn(4096, 4096, device="cuda")
-    prep = None
+    prep = prepare_dense(batches[0][0])
     for i, (c, p) in enumerate(batches):
-        _ = big @ big  # keeps the current stream busy when the pack is enqueued
-        mark = stream_mark()
-        nxt = prepare_dense(c, ready=mark)
-        assert isinstance(nxt, PreparedCones)
-        got = cone_op_prepared(nxt, p, MODE_INNER, -1.0, 0.2, outputs=ALL)
+        _ = big @ big  # a long-running kernel ahead of the step on the same stream
+        assert isinstance(prep, PreparedCones) and not prep.stale()
+        if i + 1 < len(batches):
+            prep.then(batches[i + 1][0])
+        got = cone_op_prepared(prep, p, MODE_INNER, -1.0, 0.2, check=False, outputs=ALL)  # (no host sync in the chain)
         for k in ALL:
-            assert torch.equal(got[k], want[i][k]), (i, k)
-    # hold PREP_POOL + 2 prepared batches before consuming any
-    held = [prepare_dense(c) for c, _ in batches[:PREP_POOL + 2]]
+            assert close(got[k], want[i][k]), (i, k)
+        assert bool((got["status"] == 0).all())
+        prep = prep.next
+    assert prep is None
+    # hold STEP_POOL + 2 prepared batches before consuming any
+    held = [prepare_dense(c) for c, _ in batches[:STEP_POOL + 2]]
     assert sum(h.stale() for h in held) == 2 and held[0].stale() and not held[-1].stale()
     for i, h in enumerate(held):
         got = cone_op_prepared(h, batches[i][1], MODE_INNER, -1.0, 0.2, outputs=ALL)
         for k in ALL:
-            assert torch.equal(got[k], want[i][k]), ("held", i, k)
-    # float64 cones: the conversion is this call's own work on the current stream
-    c64 = batches[0][0].double()
-    got = cone_op_prepared(prepare_dense(c64, ready=stream_mark()), batches[0][1], MODE_INNER, -1.0, 0.2, outputs=ALL)
+            assert close(got[k], want[i][k]), ("held", i, k)
+    # float64 cones: converted by the call itself
+    got = cone_op_prepared(prepare_dense(batches[0][0].double()), batches[0][1], MODE_INNER, -1.0, 0.2, outputs=ALL)
     for k in ALL:
-        assert torch.equal(got[k], want[0][k]), ("f64", k)
+        assert close(got[k], want[0][k]), ("f64", k)
 
 
-_RCCL_SCRIPT = r"""
-import json, os, sys
-sys.path[:0] = [{root!r}, os.path.join({root!r}, "tests")]
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str({port}), RANK="0", WORLD_SIZE="1")
-import torch, torch.distributed as dist
-# the process group FIRST, before any other GPU call of this process (what an N-GPU rank does)
-dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-torch.cuda.set_device(0)
-import numpy as np
-from cave_amd import synth
-from cave_amd.cave import EPO, innerConeAlignedCosine
-from cave_amd.dataset import ConeStore
-from cave_amd.dist import global_mean_loss, same_branch_seed, allreduce_grads_sum
-class M: modelSense = EPO.MINIMIZE
-ctrs, costs, _ = synth.tsp_batch(12, 48, seed=2)
-seed = same_branch_seed(4321)
-assert seed == 4321
-pred = torch.tensor(costs, device="cuda", requires_grad=True)
-c = torch.tensor(ctrs, device="cuda")
-mod = innerConeAlignedCosine(M(), solver="hip", seed=seed, reduction="none")
-per = mod(pred, c)
-g = global_mean_loss(per)            # the [sum loss, count] all-reduce over RCCL
-g.backward()
-grad_dist = pred.grad.clone()
-pred.grad = None
-mod2 = innerConeAlignedCosine(M(), solver="hip", seed=seed, reduction="mean")
-l2 = mod2(pred, c)
-l2.backward()
-red = torch.stack([per.detach().sum(), torch.tensor(float(per.numel()), device="cuda")])
-dist.all_reduce(red)
-lin = torch.nn.Linear(3, 5).cuda()
-lin(torch.ones(2, 3, device="cuda")).sum().backward()
-w0 = lin.weight.grad.clone()
-allreduce_grads_sum(lin.parameters())
-ragged = [torch.from_numpy(x[np.abs(x).sum(axis=1) > 0]) for x in ctrs]
-store = ConeStore.from_ragged_shard(ragged, 0, 1)
-o = store.cone_op(torch.arange(store.n, device="cuda"), pred.detach(), 2, -1.0, 0.2, outputs=("loss",))
-dist.barrier()
-out = dict(loss_dist=float(g), loss_plain=float(l2), grad_diff=float((grad_dist - pred.grad).abs().max()),
-           red=[float(red[0]), float(red[1])], wdiff=float((w0 - lin.weight.grad).abs().max()),
-           shard_n=store.n, shard_loss=float(o["loss"].mean()), backend=dist.get_backend())
-dist.destroy_process_group()
-print("RCCL_RESULT " + json.dumps(out))
-"""
+def test_prefetch_wraps_a_loader_and_keeps_the_loop_body():
+    """cave_amd.dataset.prefetch(loader): the loop body of code_sample.py:48-60 unchanged (fields moved with .cuda(),
+    loss = cave(cp, bctr)); losses and gradients equal those of the plain loop, every batch after the first was packed
+    by its predecessor's loss call, a ragged last batch and a loop that skips a batch both work."""
+    import torch
+
+    from cave_amd import synth
+    from cave_amd.cave import EPO, innerConeAlignedCosine
+    from cave_amd.dataset import prefetch
+    from cave_amd.qpsolver import PreparedCones
+
+    ctrs, costs, _ = synth.tsp_batch(20, 150, seed=5)
+    x = torch.randn(150, 10)
+    data = [(x[i:i + 64], torch.tensor(costs[i:i + 64]), torch.zeros(len(costs[i:i + 64]), 1), torch.zeros(len(costs[i:i + 64]), 1),
+             torch.tensor(ctrs[i:i + 64])) for i in range(0, 150, 64)]  # batches of 64, 64, 22 (host tensors, as a DataLoader yields)
+
+    class M:
+        modelSense = EPO.MINIMIZE
+
+    def run(loader, skip=None):
+        torch.manual_seed(0)
+        reg = torch.nn.Linear(10, costs.shape[1]).cuda()
+        cave = innerConeAlignedCosine(M(), solver="hip", seed=3, solve_ratio=0.7)
+        out, kinds = [], []
+        for j, batch in enumerate(loader):
+            xb, c, w, z, bctr = batch
+            xb, c, w, z, bctr = xb.cuda(), c.cuda(), w.cuda(), z.cuda(), bctr.cuda()
+            kinds.append(type(bctr).__name__)
+            if j == skip:
+                continue
+            loss = cave(reg(xb), bctr)
+            reg.zero_grad()
+            loss.backward()
+            out.append((float(loss), reg.weight.grad.clone()))
+        return out, kinds
+
+    plain, _ = run(data)
+    fused, kinds = run(prefetch(data))
+    assert kinds == ["PreparedCones"] * 3
+    assert len(plain) == len(fused) == 3
+    for (l0, g0), (l1, g1) in zip(plain, fused):
+        assert abs(l0 - l1) <= 1e-6 and float((g0 - g1).abs().max()) <= 1e-6
+    skipped, _ = run(prefetch(data), skip=1)   # batch 2's cones were attached to batch 1, which never ran its loss
+    ref, _ = run(data, skip=1)
+    for (l0, g0), (l1, g1) in zip(ref, skipped):
+        assert abs(l0 - l1) <= 1e-6 and float((g0 - g1).abs().max()) <= 1e-6
+    assert list(prefetch([])) == []
 
 
 def _free_port():
