@@ -3,9 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the fused hot path (dense scan -> projection -> CaVE+ target ->
+One "step" = one pass of the hot path (dense scan -> cone build -> projection -> CaVE+ target ->
 cosine loss -> d loss/d pred) over one batch of synthetic TSP-20 cones, B = 1024 per GPU
-(BASELINE.json configs[1]), inputs resident in HBM, through the C ABI (cave_hip_cone_dense).
+(BASELINE.json configs[1]), inputs resident in HBM, through the C ABI: ONE launch of cave_hip_cone_step
+per step -- the Newton solve + loss + gradient of batch i and, in the same grid, the scan + cone build of
+batch i+1 (whose cones a DataLoader has collated before the predictor has its prediction).
 Successive steps rotate over `--rotate` different batches (default 4 x 183 MB > the 256 MB
 Infinity Cache), so the cones of a step are read from HBM, not from a cache warmed by the step before.
 
@@ -29,16 +31,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP maps streams onto a few hardware queues (4 unless told otherwise).  With an RCCL communicator alive its streams
-# take part in that mapping and the side stream of the pack stage lands on the SAME queue as the stream of the solve:
-# the two kernels then run one after the other (195 us per step instead of 130; tools/diag/dist_step_cost.py).
-# Read by the HIP runtime when it initialises, i.e. after this line in every rank.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
-LARGE_PMC = {"tsp100": os.path.join("profiles", "r03_large_tsp100_pmc_summary.json"),
-             "sp30": os.path.join("profiles", "r03_large_sp30_pmc_summary.json")}
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
+LARGE_PMC = {"tsp100": os.path.join("profiles", "r04_large_tsp100_pmc_summary.json"),
+             "sp30": os.path.join("profiles", "r04_large_sp30_pmc_summary.json"),
+             "tsp50": os.path.join("profiles", "r04_tsp50_pmc_summary.json")}
 
 
 def parse(argv=None):
@@ -60,16 +57,10 @@ def parse(argv=None):
     ap.add_argument("--no-large-cpu", action="store_true",
                     help="skip the one-instance CPU timing of the 30x30 grid in other_configs (about a minute of host time)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="run the pack and the solve stage of a step back to back on one stream.  Default: software "
-                         "pipeline across steps -- the pack stage of step i+1 (side stream, launched behind a ~10 us "
-                         "spacer so that the solve's workgroups take their residency first) runs beside the solve "
-                         "stage of step i; every timed step still launches exactly one pack and one solve")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="force the pipelined form (default: pipelined unless the untimed self-check before the warm-up "
-                         "finds the back-to-back form faster on this machine)")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="batches the pack stage runs ahead of the solve: 1 or 2 (a DataLoader prefetch depth of 2; the slot "
-                         "pool of prepare_dense holds 3 stores)")
+                    help="time the back-to-back form as `value`: the general dense operator, pack kernel then solve kernel "
+                         "per step (what a plain `module(pred, bctr)` call launches).  Default: the fused step -- one "
+                         "launch per step holds the solve of batch i and the pack of batch i+1; every timed step still "
+                         "does one pack and one solve.  The other form is timed too and reported beside it")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at --gpus 1 (world size 1) and run the per-step "
                          "[sum loss, count] all-reduce and the sharded-store leg: the code path of an N-GPU run")
@@ -289,35 +280,29 @@ def main(argv=None):
     count = torch.full((1,), float(args.batch), device=dev)
     red_stream = torch.cuda.Stream(device=dev) if use_dist else None
 
-    from cave_amd.qpsolver import PreparedCones, cone_op_prepared, prepare_dense, stream_mark
-    args.pipeline_forced = bool(args.pipeline)   # --pipeline: no self-check, always pipelined
+    from cave_amd.qpsolver import PreparedCones, cone_op_prepared, prepare_dense
     args.pipeline = not args.no_pipeline
 
-    # Software pipeline across steps (default; --no-pipeline: the two stages back to back on one stream): the pack stage
-    # of step i+1 (stream the dense cones of the NEXT batch, build its reduced cones: depends on the cones only, which a
-    # DataLoader has collated ahead of the predictor) runs on a side stream while step i's solve kernel runs; every
-    # timed step still launches exactly one pack and one solve (the pack launched by the last timed step is for a
-    # batch nobody solves: extra work inside the timed region, none skipped).
-    state = {"q": []}
-    depth = max(1, min(2, args.pipeline_depth))  # prepared batches ahead of the solve (the slot pool holds 3 stores)
+    # Fused step (default; --no-pipeline: the general dense operator, two kernels back to back): the pack stage of
+    # batch i+1 (stream its dense cones, build its reduced cones: depends on the cones only, which a DataLoader has
+    # collated ahead of the predictor) rides in the launch of batch i's solve -- one grid, solve blocks first in the
+    # dispatch order, one stream, no events.  Every timed step does exactly one pack and one solve (the pack of the last
+    # timed step is for a batch nobody solves: extra work inside the timed region, none skipped).
+    state = {"prep": None}
 
-    def step(i):
+    def step(i, fused=None):
         _, _, c, p = batches[i % R]
-        if args.pipeline:
-            q = state["q"]
-            if not q:  # first step: the batches the pipeline is ahead by
-                q.append(prepare_dense(c))
-                for a in range(1, depth):
-                    q.append(prepare_dense(batches[(i + a) % R][2]))
-            prep = q.pop(0)
-            mark = stream_mark(dev)
+        fused = args.pipeline if fused is None else fused
+        if fused:
+            prep = state["prep"]
+            if prep is None:  # first step: nothing has packed this batch yet
+                prep = prepare_dense(c)
             if isinstance(prep, PreparedCones):
+                prep.then(batches[(i + 1) % R][2])
                 o = cone_op_prepared(prep, p, mode, -1.0, 0.2, check=False, outputs=outs)
+                state["prep"] = prep.next
             else:
                 o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
-            # enqueued AFTER the solve: the solve's workgroups take their residency first, the pack of a later
-            # batch fills what is left of each CU (one 4-wave workgroup next to four one-wave solve workgroups)
-            q.append(prepare_dense(batches[(i + depth) % R][2], ready=mark))
         else:
             o = cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
         if use_dist and "loss" in o:  # global mean loss: all-reduce of [sum loss, count]
@@ -335,30 +320,12 @@ def main(argv=None):
         return o
 
     # one status-checked call per rotating batch: lets the wrapper settle a launch shape that fits every cone of the run
+    # (and, through a checked prepared call, whether the cones qualify for the fused step)
     for _, _, c_, p_ in batches:
         cone_op_dense(c_, p_, mode, -1.0, 0.2, outputs=outs)
-    # Self-check of the pipelined form (untimed): it only pays when the solve is dispatched ahead of the pack and the two
-    # streams sit on different hardware queues -- properties of the runtime's queue mapping, not of this code.  24 steps of
-    # each form; the timed region uses the pipeline only where it is the faster one here (`pipeline.self_check`).
-    self_check = None
-    if args.pipeline and not args.pipeline_forced:
-        def probe(n=24):
-            state["q"] = []
-            for i in range(4):
-                step(i)
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for i in range(n):
-                step(i)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n
-        t_pipe = probe()
-        args.pipeline = False
-        t_b2b = probe()
-        args.pipeline = t_pipe < t_b2b
-        self_check = {"pipelined_us_per_step": 1e6 * t_pipe, "back_to_back_us_per_step": 1e6 * t_b2b,
-                      "chosen": "pipelined" if args.pipeline else "back to back"}
-        state["q"] = []
+        pr_ = prepare_dense(c_)
+        if isinstance(pr_, PreparedCones):
+            cone_op_prepared(pr_, p_, mode, -1.0, 0.2, outputs=outs)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -382,20 +349,45 @@ def main(argv=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
+    fused = bool(args.pipeline and isinstance(state["prep"], PreparedCones))
+
+    # ---- the OTHER form, timed the same way (not `value`): ADVICE r3 -- always report both
+    def timed_form(use_fused, n):
+        state["prep"] = None
+        for i in range(min(10, n)):
+            step(i, use_fused)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            step(i, use_fused)
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t) / n
+    other_us = timed_form(not args.pipeline, args.steps) if world == 1 or not use_dist else None
+
     # ---- dominant kernel duration: HIP events on the launch stream around single launches, rotating batches
+    # (fused form: the one cone_step_kernel launch of a step -- solve of batch i + pack of batch i+1; back-to-back form:
+    #  the two kernels of the general dense operator)
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5 * R)]
+    state["prep"] = None
+    step(0)
+    torch.cuda.synchronize()
     for i, (a, b) in enumerate(kev):
-        _, _, c, p = batches[i % R]
         a.record()
-        cone_op_dense(c, p, mode, -1.0, 0.2, check=False, outputs=outs)
+        step(i + 1)
         b.record()
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
     from cave_amd import qpsolver
 
     split = qpsolver._split_ok.get((m_max, d)) is True
-    kernels = ("cone_pack_kernel<4 waves> (slot mode: scan + cone build -> transient store) + "
-               "cone_packed_kernel<1 wave> (lite Newton solver + fused loss/grad)") if split else "cone_dense_kernel (fused)"
+    if fused:
+        kernels = ("cone_step_kernel<BlockCtx<2,true>> (ONE launch per step: one-wave Newton solves + fused loss/grad of batch i, "
+                   "then two-wave scan + cone build workgroups of batch i+1)")
+    elif split:
+        kernels = ("cone_pack_kernel<4 waves> (slot mode: scan + cone build -> transient store) + "
+                   "cone_packed_kernel<1 wave> (lite Newton solver + fused loss/grad)")
+    else:
+        kernels = "cone_dense_kernel (fused)"
     # algorithmic bytes per launch, dense operator format: cone once, y once, outputs once
     alg = []
     for bids, _, _, _ in batches:
@@ -403,15 +395,15 @@ def main(argv=None):
         alg.append(int((4 * m_i * d).sum() + B * (4 * d + 4 * d + 4)))
     alg_bytes = int(np.mean(alg))
     step_ms = 1e3 * dt / args.steps
-    pipelined = bool(args.pipeline and split)
-    # roofline of the step: the two kernels of consecutive steps overlap in the pipelined form, so the per-launch cost
-    # of the pair is the step time of the timed region (HIP-event time of an isolated call: kernel_ms)
-    achieved = alg_bytes / ((step_ms if pipelined else kern_ms) * 1e-3) / 1e9
+    # roofline of the dominant kernel: algorithmic bytes per launch / its average launch duration, HIP events on the
+    # launch stream around single launches (fused form: the step IS that one launch; the figure of the timed region,
+    # launches back to back, is reported beside it)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     traffic, traffic_src = None, None  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/diag/pmc_run.sh)
     try:
         pm = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
-        if pm.get("workload") == f"tsp{args.tsp}_b{args.batch}_{args.mode}" and pm.get("split") == split:
+        if pm.get("workload") == f"tsp{args.tsp}_b{args.batch}_{args.mode}" and bool(pm.get("fused")) == fused:
             traffic, traffic_src = pm.get("hbm_bytes_per_launch"), PMC_SUMMARY
     except Exception:  # noqa: BLE001
         pass
@@ -428,21 +420,22 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernels, "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
-                         "frac_isolated_call": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernel_ms_note": "kernel_ms: HIP events around ONE isolated operator call = every kernel of the "
-                                           "step back to back (the split form launches two); achieved / frac: "
-                                           + ("algorithmic bytes / step time of the timed region (pack of step i+1 beside "
-                                              "the solve of step i)" if pipelined else "algorithmic bytes / kernel_ms")
-                                           + "; per-kernel durations: profiles/r03_kernel_stats.csv",
+                         "frac_timed_region": alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_note": "kernel_ms: average of HIP-event times around single launches of the step "
+                                           "(rotating batches); achieved / frac = algorithmic bytes / kernel_ms; "
+                                           "frac_timed_region = algorithmic bytes / ms_per_step (launches back to back, "
+                                           "host time included); per-kernel durations: profiles/r04_kernel_stats.csv",
                          "memory_level": f"HBM (the {R} rotating batches exceed the 256 MB Infinity Cache)" if
                          R * ctrs.numel() * 4 > 300e6 else "may be served by the Infinity Cache (working set < 256 MB)"},
             "newton_iters_mean": float(o["iters"].float().mean()), "newton_iters_max": int(o["iters"].max()),
-            "pipeline": {"across_steps": pipelined, "depth": depth if pipelined else 0, "self_check": self_check,
-                         "unpipelined_ms_per_step": kern_ms,
-                         "note": "the pack stage of step i+1 runs on a side stream beside the solve stage of step i "
-                                 "(cave_amd.qpsolver.prepare_dense(next, ready=stream_mark())), behind a ~10 us spacer "
-                                 "kernel so that the solve is dispatched first and keeps its residency; every timed step "
-                                 "launches one pack and one solve; --no-pipeline runs them back to back"},
+            "pipeline": {"form": "fused step (one launch: solve of batch i + pack of batch i+1)" if fused else
+                         "back to back (general dense operator: pack kernel, then solve kernel)",
+                         "fused_us_per_step": 1e3 * step_ms if fused else other_us,
+                         "back_to_back_us_per_step": other_us if fused else 1e3 * step_ms,
+                         "streams": 1, "events": 0,
+                         "note": "both forms are timed over the same number of steps; `value` is the form named in `form` "
+                                 "(--no-pipeline selects the other).  The fused form needs the NEXT batch's cones at the "
+                                 "loss call: cave_amd.dataset.prefetch(loader) or loss_fn.prepare(bctr, next_bctr)"},
         }
         if use_dist:
             res["process_group"] = {"backend": "nccl (RCCL)", "world_size": world,
@@ -533,53 +526,49 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
                                         "unit": "GB/s", "frac": pk_bytes / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "kernel": "cone_packed_kernel"}}
 
-    # training step in the shape of code_sample.py:23-59: linear predictor, CaVE+ loss, Adam(lr 1e-2)
+    # training step in the shape of code_sample.py:23-59: linear predictor, CaVE+ loss, Adam(lr 1e-2).
+    # Two implementations of the same optimizer are timed: torch.optim.Adam(fused=True) -- one kernel per step -- under the
+    # plain keys, and the default (foreach: a dozen small kernels, ~0.1 ms of host time per step) under *_foreach_adam_*.
     class _Model:
         modelSense = EPO.MINIMIZE
 
     p_feat = 10
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(len(ids), p_feat, generator=g).to(dev)
-    reg = torch.nn.Linear(p_feat, pred.shape[1]).to(dev)
-    opt = torch.optim.Adam(reg.parameters(), lr=1e-2)
-    cave = innerConeAlignedCosine(_Model(), solver="hip", seed=0)
     batch = PackedBatch(store, tid)
-
-    def train_step():
-        loss = cave(reg(x), batch)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
-
-    for _ in range(5):
-        train_step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(50):
-        train_step()
-    torch.cuda.synchronize()
-    out["train_step_ms"] = 1e3 * (time.perf_counter() - t0) / 50
-    # same step, per-instance status examined one call later instead of right after the launch (no host sync per step)
     from cave_amd.cave import flush_checks
 
+    def time_train(kw, fused_adam, n=100):
+        reg = torch.nn.Linear(p_feat, pred.shape[1]).to(dev)
+        opt = torch.optim.Adam(reg.parameters(), lr=1e-2, fused=fused_adam)
+        cave = innerConeAlignedCosine(_Model(), solver="hip", seed=0, solver_kwargs=kw)
+
+        def train_step():
+            loss = cave(reg(x), batch)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        for _ in range(10):
+            train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            train_step()
+        flush_checks()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    out["train_step_ms"] = time_train(None, True)
+    out["train_step_foreach_adam_ms"] = time_train(None, False)
+    # same step, per-instance status examined by a later call, once it has arrived (no host sync per step)
+    out["train_step_lazy_check_ms"] = time_train({"check": "lazy"}, True)
+    out["train_step_lazy_check_foreach_adam_ms"] = time_train({"check": "lazy"}, False)
+    out["train_step_optimizer"] = ("torch.optim.Adam(lr=1e-2, fused=True); *_foreach_adam_*: torch.optim.Adam(lr=1e-2), the "
+                                   "default multi-tensor implementation (rounds 1-3 timed that one)")
+    reg = torch.nn.Linear(p_feat, pred.shape[1]).to(dev)
+    opt = torch.optim.Adam(reg.parameters(), lr=1e-2, fused=True)
     cave_lazy = innerConeAlignedCosine(_Model(), solver="hip", seed=0, solver_kwargs={"check": "lazy"})
-
-    def train_step_lazy():
-        loss = cave_lazy(reg(x), batch)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-
-    for _ in range(5):
-        train_step_lazy()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(50):
-        train_step_lazy()
-    flush_checks()
-    torch.cuda.synchronize()
-    out["train_step_lazy_check_ms"] = 1e3 * (time.perf_counter() - t0) / 50
     # the same steps with the store's warm start (multipliers of the previous solve of each instance): cones are
     # static and the predictor moves a little per Adam step
     wstore = ConeStore.from_dense(torch.tensor(ctrs_np))
@@ -613,9 +602,9 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
     out["packed_store_warm_start_kernel_ms"] = float(np.mean([a.elapsed_time(b) for a, b in kev]))
     # the same step captured in a HIP graph (the C-ABI launch path does no allocation, attribute
     # change or host sync of its own when status checking is deferred)
-    try:
+    def time_graph(fused_adam):
         reg2 = torch.nn.Linear(p_feat, pred.shape[1]).to(dev)
-        opt2 = torch.optim.Adam(reg2.parameters(), lr=1e-2, capturable=True)
+        opt2 = torch.optim.Adam(reg2.parameters(), lr=1e-2, capturable=True, fused=fused_adam)
         cave2 = innerConeAlignedCosine(_Model(), solver="hip", seed=0, solver_kwargs={"check": False})
 
         def step2():
@@ -642,10 +631,13 @@ def extras(args, ctrs_np, costs_np, ids, pred, dev, mode, outs):
         for _ in range(100):
             graph.replay()
         torch.cuda.synchronize()
-        out["train_step_graph_ms"] = 1e3 * (time.perf_counter() - t0) / 100
-        out["train_step_graph_loss"] = float(gl.detach())
-    except Exception as e:  # noqa: BLE001 - graph capture is an optional extra
-        out["train_step_graph_error"] = repr(e)[:200]
+        return 1e3 * (time.perf_counter() - t0) / 100, float(gl.detach())
+
+    for key, fused_adam in (("train_step_graph", True), ("train_step_graph_foreach_adam", False)):
+        try:
+            out[key + "_ms"], out[key + "_loss"] = time_graph(fused_adam)
+        except Exception as e:  # noqa: BLE001 - graph capture is an optional extra
+            out[key + "_error"] = repr(e)[:200]
     return out
 
 
@@ -659,7 +651,7 @@ def other_configs(dev, large_cpu=True):
     from cave_amd import _lib, synth
     from cave_amd.dataset import ConeStore
 
-    def run(name, kind, size, B, mode, chunk, cpu_n, cpu_note, tag=None, cpu_recorded=None):
+    def run(name, kind, size, B, mode, chunk, cpu_n, cpu_note, tag=None, cpu_recorded=None, hybrid_ratio=None):
         items, costs, _ = synth.coo_batch(kind, size, B, seed=0)
         d = int(costs.shape[1])
         m_max = max(it[3] for it in items)
@@ -697,9 +689,27 @@ def other_configs(dev, large_cpu=True):
                 pm = json.load(open(os.path.join(ROOT, LARGE_PMC[tag])))
                 res["roofline"]["traffic"] = pm.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = LARGE_PMC[tag] + " (tools/diag/pmc_run_large.sh, same batch)"
+                res["roofline"]["traffic_note"] = pm.get("fetch_size_note")
                 res["roofline"]["traffic_over_algorithmic"] = pm.get("hbm_bytes_per_launch") / alg
             except Exception:  # noqa: BLE001
                 pass
+        if hybrid_ratio is not None:
+            # CaVE Hybrid (src/cave.py:197-204): one RNG draw per forward decides the branch of the whole batch -- the QP
+            # branch timed above with probability solve_ratio, else the heuristic branch (no projection: one pass over
+            # y and the stored average normal); the expected step is their mix
+            kh = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+            store.cone_op(ids, pred, _lib.MODE_HEURISTIC, -1.0, 0.2, outputs=outs)
+            for a, b in kh:
+                a.record()
+                store.cone_op(ids, pred, _lib.MODE_HEURISTIC, -1.0, 0.2, check=False, outputs=outs)
+                b.record()
+            torch.cuda.synchronize()
+            h_ms = float(np.mean([a.elapsed_time(b) for a, b in kh]))
+            res["hybrid"] = {"solve_ratio": hybrid_ratio, "qp_branch_ms": k_ms, "heuristic_branch_ms": h_ms,
+                             "hybrid_expected_ms_per_step": hybrid_ratio * k_ms + (1.0 - hybrid_ratio) * h_ms,
+                             "hybrid_expected_projections_per_s": B / (1e-3 * (hybrid_ratio * k_ms + (1.0 - hybrid_ratio) * h_ms)),
+                             "note": "kernel times (HIP events); the branch is drawn once per forward for the whole batch "
+                                     "(src/cave.py:201), so a step costs one or the other"}
         if store.large and B > 256:
             # the slowest instance beside the mean: 256 instances = one workgroup per compute unit, so the launch
             # time is the latency of its slowest instance; mean = whole-batch time x resident workgroups / batch
@@ -755,10 +765,10 @@ def other_configs(dev, large_cpu=True):
     out = []
     specs = [
         dict(name="configs[2] TSP-50, CaVE Exact, 4096/8 GPUs", kind="tsp", size=50, B=512, mode=_lib.MODE_EXACT, chunk=32,
-             cpu_n=2, cpu_note=""),
+             cpu_n=2, cpu_note="", tag="tsp50"),
         # one TSP-100 projection takes scipy.optimize.nnls 26 minutes: recorded once (with the fixture), not re-timed per run
         dict(name="configs[3] TSP-100, QP branch of CaVE Hybrid (inner_ratio 0.2), 2048/4 GPUs", kind="tsp", size=100, B=512,
-             mode=_lib.MODE_INNER, chunk=4, cpu_n=0, cpu_note="", tag="tsp100",
+             mode=_lib.MODE_INNER, chunk=4, cpu_n=0, cpu_note="", tag="tsp100", hybrid_ratio=0.3,
              cpu_recorded={"value": 1.0 / (26 * 60), "unit": "projections/s", "cores": 1, "kind": "reference",
                            "sample": "RECORDED, not timed in this run: scipy.optimize.nnls (the reference's solver, "
                                      "src/cave.py:307) on 1 TSP-100 instance took 26 min when tests/golden/large.npz was "

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "cave_hip_packed_lds_bytes",
     "cave_hip_large_slice_bytes", "cave_hip_packed_large_slice_bytes", "cave_hip_cone_dense_large",
     "cave_hip_pack_large", "cave_hip_cone_packed_large", "cave_hip_packed_large_lds_bytes",
-    "cave_hip_step_lds_bytes", "cave_hip_cone_step",
+    "cave_hip_step_lds_bytes", "cave_hip_cone_step", "cave_hip_lite_from_packed",
 )
 
 
@@ -148,9 +148,11 @@ def load_library() -> C.CDLL:
         getattr(lib, name).restype = C.c_int32
     lib.cave_hip_step_lds_bytes.argtypes = [i64, i64]
     lib.cave_hip_step_lds_bytes.restype = i32
-    lib.cave_hip_cone_step.argtypes = [C.POINTER(LiteStore), vp, i64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp,
+    lib.cave_hip_cone_step.argtypes = [C.POINTER(LiteStore), vp, vp, i64, i32, f32, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp,
                                        vp, i64, i64, i64, C.POINTER(LiteStore), vp, vp, vp]
     lib.cave_hip_cone_step.restype = i32
+    lib.cave_hip_lite_from_packed.argtypes = [C.POINTER(Store), C.POINTER(LiteStore), vp, vp]
+    lib.cave_hip_lite_from_packed.restype = i32
     _lib = lib
     return lib
 

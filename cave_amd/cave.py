@@ -48,29 +48,46 @@ def _op_kwargs(kwargs: dict) -> dict:
 
 # ---- deferred status checks (solver_kwargs={"check": "lazy"})
 # Reading the per-instance status back right after the launch costs a host sync per step, which exposes the launch
-# latency of everything else in an eager training step (0.54 -> 0.35 ms at TSP-20 / B = 1024).  In lazy mode the
-# status is copied to pinned memory asynchronously and examined at the next loss call (or by flush_checks()), so a
-# failing instance still raises -- one call later.
+# latency of everything else in an eager training step.  In lazy mode the status is copied to pinned memory
+# asynchronously and examined by a LATER loss call, once its copy has arrived (or by flush_checks()), so a failing
+# instance still raises -- a call or two later.  A later call never WAITS for a verdict (round 3 did, at the next call:
+# the host could then not run ahead of the GPU by more than one step, 0.45 ms per step against 0.31 unchecked); only when
+# more than LAZY_MAX_PENDING verdicts are outstanding does it wait for the oldest.
 _pending_checks: list = []
+LAZY_MAX_PENDING = 4
+
+
+def _examine(host, what, shape) -> None:
+    from . import _lib as L
+    from .qpsolver import _raise_for_status, forget_shape
+
+    _pinned_free.setdefault(host.numel(), []).append(host)  # pinned allocations are slow: keep them
+    if not bool(host.any()):  # every status CAVE_ST_OK (= 0): the common case costs one reduction on the host
+        return
+    if shape is not None and bool((host == L.ST_TOO_LARGE).any()):
+        forget_shape(*shape)
+    _raise_for_status(host, what)
 
 
 def flush_checks() -> None:
-    """Examine the status of every lazily checked launch so far; raises like the strict check would have.
+    """Examine the status of every lazily checked launch so far (waits for them); raises like the strict check would.
 
     A launch whose cached shape (waves / LDS tier per (m_max, d)) turned out too small for a later batch
     forgets that shape first, so the next call for it runs status-checked and re-tiers (two waves, full
     arena, large-cone path) instead of failing again.  The failed instances of the lazy launch itself
     contributed zero loss and zero gradient (masked on the device), so no NaN reached the optimizer."""
-    from . import _lib as L
-    from .qpsolver import _raise_for_status, forget_shape
-
     while _pending_checks:
         host, event, what, shape = _pending_checks.pop(0)
         event.synchronize()
-        _pinned_free.setdefault(host.numel(), []).append(host)  # pinned allocations are slow: keep them
-        if shape is not None and bool((host == L.ST_TOO_LARGE).any()):
-            forget_shape(*shape)
-        _raise_for_status(host, what)
+        _examine(host, what, shape)
+
+
+def _poll_checks() -> None:
+    """The verdicts that have arrived, without waiting (beyond LAZY_MAX_PENDING outstanding: the oldest is awaited)."""
+    while _pending_checks and (_pending_checks[0][1].query() or len(_pending_checks) > LAZY_MAX_PENDING):
+        host, event, what, shape = _pending_checks.pop(0)
+        event.synchronize()
+        _examine(host, what, shape)
 
 
 _pinned_free: dict = {}
@@ -93,13 +110,13 @@ class _ConeLossFunction(torch.autograd.Function):
         kwargs = _op_kwargs(kwargs)
         lazy = kwargs.get("check") == "lazy"
         if lazy:
-            flush_checks()  # the previous call's verdict
+            _poll_checks()  # the verdicts of earlier calls that have arrived
             kwargs = dict(kwargs, check=False)
         if isinstance(tight_ctrs, PackedBatch):  # device-resident cones, ids only (cave_amd/dataset.py)
-            o = tight_ctrs.store.cone_op(tight_ctrs.ids, pred_cost, mode, sign, inner_ratio,
+            o = tight_ctrs.store.cone_op(tight_ctrs.ids, pred_cost, mode, sign, inner_ratio, zero_failed=lazy,
                                          outputs=("loss", "grad"), **_packed_kwargs(kwargs))
         elif isinstance(tight_ctrs, PreparedCones):  # dense batch whose pack stage ran ahead (qpsolver.prepare_dense)
-            o = cone_op_prepared(tight_ctrs, pred_cost, mode, sign, inner_ratio, outputs=("loss", "grad"),
+            o = cone_op_prepared(tight_ctrs, pred_cost, mode, sign, inner_ratio, zero_failed=lazy, outputs=("loss", "grad"),
                                  **_packed_kwargs(kwargs))
         else:
             if lazy and not _dense_shape_settled(tight_ctrs):
@@ -110,11 +127,13 @@ class _ConeLossFunction(torch.autograd.Function):
         if lazy:
             shape = None if isinstance(tight_ctrs, PackedBatch) else (int(tight_ctrs.shape[1]), int(tight_ctrs.shape[2]))
             _defer_check(o["status"], "solver='hip' (lazy check)", shape)
-            # the verdict arrives one call late: until then a failed instance (NaN-filled outputs) must not
-            # reach the optimizer -- mask it on the device (no host sync)
-            ok = o["status"] == 0
-            loss = torch.where(ok, loss, torch.zeros_like(loss))
-            grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
+            # the verdict arrives a call or two late: until then a failed instance (NaN-filled outputs) must not reach
+            # the optimizer.  The step kernel zeroes its loss and gradient itself (CAVE_STEP_ZERO_FAILED); after the
+            # other kernels it is masked here, on the device (no host sync either way)
+            if not o.get("zero_failed"):
+                ok = o["status"] == 0
+                loss = torch.where(ok, loss, torch.zeros_like(loss))
+                grad = torch.where(ok.unsqueeze(1), grad, torch.zeros_like(grad))
         ctx.save_for_backward(grad)
         ctx.pred_meta = (pred_cost.device, pred_cost.dtype)
         return loss.to(device=pred_cost.device, dtype=pred_cost.dtype)

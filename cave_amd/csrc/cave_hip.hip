@@ -318,8 +318,8 @@ static bool lite_store_ok(const cave_lite_store* s, int64_t need, int64_t d) {
          (((uintptr_t)s->ell | (uintptr_t)s->csr16) & 15u) == 0 && ((4 * d) & 3) == 0;
 }
 
-int32_t cave_hip_cone_step(const cave_lite_store* solve, const float* pred, int64_t B, int32_t mode, float sign,
-                           float inner_ratio, int32_t max_iter, float* proj, float* rnorm, float* target, float* loss,
+int32_t cave_hip_cone_step(const cave_lite_store* solve, const int64_t* ids, const float* pred, int64_t B, int32_t mode, float sign,
+                           float inner_ratio, int32_t max_iter, int32_t flags, float* proj, float* rnorm, float* target, float* loss,
                            float* grad, int32_t* status, int32_t* iters, const float* next_ctrs, int64_t B_next,
                            int64_t m_max, int64_t d, const cave_lite_store* next, int32_t* pack_status,
                            uint32_t* cu_tickets, void* stream) {
@@ -332,9 +332,10 @@ int32_t cave_hip_cone_step(const cave_lite_store* solve, const float* pred, int6
   if (B > 0) {
     if (mode < CAVE_MODE_PROJECT || mode > CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_step: bad mode (PROJECT .. AVG)");
     if (!pred && mode != CAVE_MODE_AVG) return fail(CAVE_E_INVALID, "cone_step: pred is null");
-    if (!lite_store_ok(solve, B, d)) return fail(CAVE_E_INVALID, "cone_step: bad solve store (size, d, null or unaligned array)");
-    P.S.store = *solve; P.S.pred = pred; P.S.B = B; P.S.mode = mode; P.S.sign = sign; P.S.inner_ratio = inner_ratio;
+    if (!lite_store_ok(solve, ids ? 1 : B, d)) return fail(CAVE_E_INVALID, "cone_step: bad solve store (size, d, null or unaligned array)");
+    P.S.store = *solve; P.S.ids = ids; P.S.pred = pred; P.S.B = B; P.S.mode = mode; P.S.sign = sign; P.S.inner_ratio = inner_ratio;
     P.S.max_iter = max_iter > 0 ? max_iter : 100;
+    P.S.flags = flags;
     P.S.o = OutPtrs{proj, rnorm, target, loss, grad, status, iters};
   }
   int32_t cap = 0, lds = 0;
@@ -352,6 +353,22 @@ int32_t cave_hip_cone_step(const cave_lite_store* solve, const float* pred, int6
   P.tickets = cu_tickets;
   hipError_t e = launch_step((unsigned)(B + B_next), (uint32_t)lds, (hipStream_t)stream, P);
   if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch cone_step_kernel", e);
+  return CAVE_OK;
+}
+
+int32_t cave_hip_lite_from_packed(const cave_cone_store* src, const cave_lite_store* dst, int32_t* status, void* stream) {
+  if (!src || !dst) return fail(CAVE_E_INVALID, "lite_from_packed: null store");
+  if (src->n == 0) return CAVE_OK;
+  if (src->n < 0 || src->n >= (int64_t)1 << 31 || src->d <= 0 || src->d > kLiteMaxD)
+    return fail(CAVE_E_INVALID, "lite_from_packed: need 0 < d <= 256, n < 2^31");
+  if (!lite_store_ok(dst, src->n, src->d)) return fail(CAVE_E_INVALID, "lite_from_packed: bad lite store (size, d, null or unaligned array)");
+  const int64_t d = src->d;
+  const uint64_t lds = 256 + 64 + align8u(4 * d) + align8u(d) + align8u(4 * (d + 1)) + align8u(4 * (kLiteMaxRows + 1)) + 64 +
+                       2 * align8u(2 * 64 * kLiteMaxChunk) + lite_lds_bytes((int)d, 64u * kLiteMaxChunk) + 64;
+  LiteFromPackedParams P;
+  P.src = *src; P.dst = *dst; P.n = src->n; P.lds_bytes = (uint32_t)lds; P.status = status;
+  hipError_t e = launch_lite_from_packed((unsigned)src->n, (uint32_t)lds, (hipStream_t)stream, P);
+  if (e != hipSuccess) return fail(CAVE_E_LAUNCH, "launch lite_from_packed_kernel", e);
   return CAVE_OK;
 }
 

@@ -95,7 +95,7 @@ CAVE_HD int32_t scan_and_build(C& c, Arena& ar, ConeBuild& cb, const float* A, i
   c.sync();
   CAVE_T0();
   uint32_t nnz;  // (erc = flat index for now)
-  if constexpr (DEEP) nnz = c.template scan_dense_sparse<16>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);
+  if constexpr (DEEP) nnz = c.template scan_dense_sparse<8>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);
   else nnz = c.template scan_dense<LARGE>(A, (uint32_t)m * (uint32_t)d, cb.erc, cb.eall, cap);
   c.sync();
   CAVE_ACC(10);

@@ -300,11 +300,13 @@ struct BlockCtx {
   // per KiB chunk whatever it holds; here a chunk costs ~8 when it is empty (one OR-test + ballot), ~45 when no lane
   // holds more than one non-zero (ONE ballot + mbcnt gives the slots; the lanes with a non-zero store it under their
   // exec mask), the full four-ballot form only when some lane's float4 holds two or more (runs of consecutive edges
-  // in TSP degree / cut rows).  U = 16: 32 KiB in flight per wave (a lone workgroup per compute unit is bound by
-  // memory latency, ~5 k cycles per round trip: tools/micro/stream_wg.hip).
-  // Tried and dropped (round 4, same pack-only timing within 5 %: the pack is bound by waits, not by this loop's
-  // instruction count -- SQ_WAIT_ANY 52 %, SQ_WAIT_INST_ANY 20 % of its wave cycles): dword loads with one element
-  // per lane and the whole share of a wave resident in registers (one ballot per 64 floats, one barrier per round).
+  // in TSP degree / cut rows).  U = 8 KiB per wave per batch: deeper batches (16: 32 KiB in flight per wave) shorten a
+  // LONE workgroup's scan (tools/micro/stream_wg.hip: ~5 k cycles of memory latency per round trip) but not the
+  // step kernel's, which runs two to four pack workgroups per compute unit beside the solve waves and is bound by
+  // issue and instruction fetch (SQ_WAIT_INST_ANY 20 % of its wave cycles): U = 4 / 8 / 16 -> pack-only launch 66.4 /
+  // 66.5 / 71.9 us, fused step 133.5 / 133.2 / 135.7 us.
+  // Tried and dropped (round 4, same timing within 5 %): dword loads with one element per lane and a wave's whole
+  // share resident in registers (one ballot per 64 floats, one barrier per round, buffer-load range checks).
   template <int U>
   __device__ __forceinline__ uint32_t scan_dense_sparse(const float* __restrict__ A, uint32_t n, uint32_t* eflat, float* eval,
                                                         uint32_t cap) {

@@ -244,6 +244,16 @@ __global__ __launch_bounds__(CP::NT, 2) void cone_step_kernel(StepParams P) {
 #endif
 }
 
+// packed cone store -> lite store, one workgroup per instance (run once per store: cones are static)
+template <class C>
+__global__ CAVE_BOUNDS(C) void lite_from_packed_kernel(LiteFromPackedParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C c;
+  c.init(smem);
+  const int64_t b = blockIdx.x;
+  if (b < P.n) run_lite_from_packed(c, smem, P, b);
+}
+
 // ---------------------------------------------------------------- launch table (host)
 // One function per kernel shape, defined next to its instantiation (k_*.hip).  Each sets the dynamic-LDS
 // attribute when the launch needs more than 48 KiB, launches on `stream` and returns hipGetLastError().
@@ -269,6 +279,7 @@ CAVE_DECL_LAUNCH_LARGE(launch_packed_large_w1, PackedParams);
 CAVE_DECL_LAUNCH_LARGE(launch_packed_large_w2, PackedParams);
 CAVE_DECL_LAUNCH_LARGE(launch_packed_large_w4, PackedParams);
 CAVE_DECL_LAUNCH(launch_step, StepParams);
+CAVE_DECL_LAUNCH(launch_lite_from_packed, LiteFromPackedParams);
 
 template <class K>
 static inline hipError_t ensure_lds(K kernel, uint32_t bytes) {

@@ -204,7 +204,25 @@ class ConeStore:
         self.large_lds = int(lib.cave_hip_packed_large_lds_bytes(int(self.max_rows), int(self.max_bw))) if self.large else 0
         if self.large:
             self._fold_signs()
+        self._build_lite()
         return self
+
+    def _build_lite(self) -> None:
+        """Cones are static per instance (src/dataset.py:72): when every instance qualifies for the one-wave solver,
+        build its index structures ONCE -- a lite store beside the packed one (cave_hip_lite_from_packed) -- and serve
+        batches of up to 2048 ids through the solve half of the step kernel (cave_hip_cone_step: 7 KB per instance in
+        one memory round trip, no per-call build of the structures, the lite-only code object)."""
+        from .qpsolver import _LiteSlots
+
+        self.lite_slots = None
+        if not self.lite or self.large or self.n == 0:
+            return
+        lib = _lib.load()
+        ls = _LiteSlots(self.device, self.n, self.d)
+        _lib.check(lib.cave_hip_lite_from_packed(C.byref(self._c), ls.ref, _lib.ptr(ls.pack_status), _lib.current_stream()),
+                   "cave_hip_lite_from_packed")
+        if bool((ls.pack_status == 0).all()):
+            self.lite_slots = ls
 
     def _fold_signs(self) -> None:
         """Large path only (it reads the store in place, every Newton iteration): for instances whose entries are all
@@ -290,18 +308,30 @@ class ConeStore:
         return int(12 * nz + 9 * rows + B * (self.d * (1 + 4) + 4 * (self.d + 1) + 8 * self.d + 4))
 
     def cone_op(self, ids: torch.Tensor, pred_cost: torch.Tensor | None, mode: int, sign: float = 1.0,
-                inner_ratio: float = 0.2, *, max_iter: int = 0, check: bool = True,
+                inner_ratio: float = 0.2, *, max_iter: int = 0, check: bool = True, zero_failed: bool = False,
                 outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
+        """`zero_failed`: ask the kernel to write loss 0 / gradient 0 for instances whose status is not OK (the lite
+        slots' kernel can: out["zero_failed"] is then set; callers mask the others themselves)."""
         lib = _lib.load()
         dev = self.device
-        ids = ids.to(device=dev, dtype=torch.int64).contiguous()
+        # (every conversion below is skipped when the tensor already is what the kernel reads: a training step is
+        #  host-bound, and each no-op .to() / .contiguous() costs a microsecond or two of it)
+        if ids.device != dev or ids.dtype != torch.int64 or not ids.is_contiguous():
+            ids = ids.to(device=dev, dtype=torch.int64).contiguous()
         B, d = int(ids.numel()), self.d
-        pred = None if pred_cost is None else pred_cost.detach().to(device=dev, dtype=torch.float32).contiguous()
+        pred = None
+        if pred_cost is not None:
+            pred = pred_cost.detach()
+            if pred.device != dev or pred.dtype != torch.float32 or not pred.is_contiguous():
+                pred = pred.to(device=dev, dtype=torch.float32).contiguous()
         out: dict[str, torch.Tensor] = {}
-        with torch.cuda.device(dev):
+        other_device = torch.cuda.current_device() != dev.index
+        if other_device:
+            ctx = torch.cuda.device(dev)
+            ctx.__enter__()
+        try:
             for name in outputs:
-                shape = (B,) if name in ("rnorm", "loss") else (B, d)
-                out[name] = torch.empty(shape, dtype=torch.float32, device=dev)
+                out[name] = torch.empty((B,) if name in ("rnorm", "loss") else (B, d), dtype=torch.float32, device=dev)
             status = torch.empty(B, dtype=torch.int32, device=dev)
             iters = torch.empty(B, dtype=torch.int32, device=dev)
             out["status"], out["iters"] = status, iters
@@ -318,6 +348,14 @@ class ConeStore:
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())
                 _lib.check(rc, "cave_hip_cone_packed_large")
+            elif (self.lite_slots is not None and B <= 2048 and mode != _lib.MODE_INNER_IPM and not self.warm_start
+                  and self.waves == 0):
+                from .qpsolver import _launch_step
+
+                _launch_step(self.lite_slots, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, None, None, ids=ids,
+                             zero_failed=zero_failed)
+                if zero_failed:
+                    out["zero_failed"] = True
             else:
                 rc = lib.cave_hip_cone_packed(
                     C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
@@ -326,9 +364,13 @@ class ConeStore:
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())
                 _lib.check(rc, "cave_hip_cone_packed")
-            self.last_iters = iters  # Newton iterations of the most recent call (device tensor; diagnostics)
+            self.last_iters = iters  # Newton iterations / status of the most recent call (device tensors; diagnostics)
+            self.last_status = status
             if check:
                 _raise_for_status(status, "solver='hip' (packed)")
+        finally:
+            if other_device:
+                ctx.__exit__(None, None, None)
         return out
 
 

@@ -171,7 +171,8 @@ _tickets: dict = {}
 
 
 class _LiteSlots:
-    """B slots of a cave_lite_store (include/cave_hip.h) + the pack status of the batch it holds."""
+    """B slots of a cave_lite_store (include/cave_hip.h) + the pack status of the batch it holds (or, for a
+    device-resident ConeStore, of all its instances)."""
 
     def __init__(self, dev, B: int, d: int):
         import ctypes as C
@@ -267,12 +268,14 @@ def _step_qualifies(t) -> bool:
     return 0 < m and d <= SPLIT_MAX_D and 0 < B <= STEP_MAX_B and _step_ok.get((m, d)) is not False and step_lds_bytes(m, d) > 0
 
 
-def _launch_step(solve, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, nxt_ctrs, nxt_store):
+def _launch_step(solve, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, nxt_ctrs, nxt_store, ids=None,
+                 zero_failed=False):
     lib = _lib.load()
     Bn, mn, dn = (nxt_ctrs.shape if nxt_ctrs is not None else (0, 0, solve.d))
-    dev = pred.device if pred is not None else nxt_ctrs.device
+    dev = status.device if status is not None else nxt_ctrs.device
     rc = lib.cave_hip_cone_step(
-        solve.ref if solve is not None else None, _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio), int(max_iter),
+        solve.ref if solve is not None else None, _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
+        int(max_iter), 1 if zero_failed else 0,
         _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")), _lib.ptr(out.get("loss")),
         _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
         _lib.ptr(nxt_ctrs), Bn, mn, dn, nxt_store.ref if nxt_store is not None else None,
@@ -296,7 +299,7 @@ def prepare_dense(tight_ctrs: torch.Tensor) -> "PreparedCones | torch.Tensor":
 
 
 def cone_op_prepared(prep: PreparedCones, pred_cost: torch.Tensor, mode: int, sign: float = 1.0, inner_ratio: float = 0.2, *,
-                     max_iter: int = 0, check: bool = True,
+                     max_iter: int = 0, check: bool = True, zero_failed: bool = False,
                      outputs: tuple[str, ...] = ("proj", "rnorm")) -> dict[str, torch.Tensor]:
     """The solve stage for a prepared batch (same outputs as cone_op_dense) and, in the same launch, the pack stage of
     the batch attached with `prep.then(...)`, whose PreparedCones is left in `prep.next`.  A batch with a cone the lite
@@ -329,7 +332,10 @@ def cone_op_prepared(prep: PreparedCones, pred_cost: torch.Tensor, mode: int, si
                 prep.next = PreparedCones(nctrs, nstore, nstore.gen)
             else:
                 prep.next = follow
-        _launch_step(prep.store, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, nctrs, nstore)
+        _launch_step(prep.store, pred, B, mode, sign, inner_ratio, max_iter, out, status, iters, nctrs, nstore,
+                     zero_failed=zero_failed)
+        if zero_failed:
+            out["zero_failed"] = True  # (the kernel wrote loss 0 / gradient 0 for instances whose status is not OK)
         if check:
             if bool((status == ST_TOO_LARGE).any()):
                 _step_ok[(m, d)] = False

@@ -269,18 +269,27 @@ typedef struct cave_lite_store {
  * qualify (d > 256, or five workgroups would not fit a compute unit: use the general operators) */
 int32_t cave_hip_step_lds_bytes(int64_t m_max, int64_t d);
 
-/* Solve half: instances [0, B) of `solve` (packed by an earlier call) with predictions pred [B, d]; outputs as
- *   cave_hip_cone_dense (modes PROJECT / EXACT / INNER / HEURISTIC / AVG; an instance whose slot holds no cone reports
- *   CAVE_ST_TOO_LARGE).  B = 0 (solve may be NULL): pack only.
+/* Solve half: B instances of `solve` -- slot ids[b], or slot b when ids is NULL (a transient per-batch store packed
+ *   by an earlier call) -- with predictions pred [B, d]; outputs as cave_hip_cone_dense (modes PROJECT / EXACT / INNER /
+ *   HEURISTIC / AVG; an instance whose slot holds no cone reports CAVE_ST_TOO_LARGE, a slot out of range
+ *   CAVE_ST_BAD_INPUT).  B = 0 (solve may be NULL): pack only.
  * Pack half: instances [0, B_next) of next_ctrs [B_next, m_max, d] into slots [0, B_next) of `next` (a different
  *   store than `solve`); pack_status [B_next] or NULL.  B_next = 0 (next_ctrs / next may be NULL): solve only.
  * cu_tickets: 4096 uint32 of device memory, zeroed once by the caller, shared by the launches of one device (per
  *   compute-unit counters that spread the solve waves over the SIMDs; the library keeps no state of its own). */
-int32_t cave_hip_cone_step(const cave_lite_store* solve, const float* pred, int64_t B, int32_t mode, float sign,
-                           float inner_ratio, int32_t max_iter, float* proj, float* rnorm, float* target, float* loss,
+#define CAVE_STEP_ZERO_FAILED 1 /* flags: an instance whose status is not CAVE_ST_OK gets loss 0 and a zero gradient (a
+                                * training loop that examines `status` a step later must not feed NaN to its optimizer) */
+int32_t cave_hip_cone_step(const cave_lite_store* solve, const int64_t* ids, const float* pred, int64_t B, int32_t mode, float sign,
+                           float inner_ratio, int32_t max_iter, int32_t flags, float* proj, float* rnorm, float* target, float* loss,
                            float* grad, int32_t* status, int32_t* iters, const float* next_ctrs, int64_t B_next,
                            int64_t m_max, int64_t d, const cave_lite_store* next, int32_t* pack_status,
                            uint32_t* cu_tickets, void* stream);
+
+/* Device-resident stores: cones are static per instance (src/dataset.py:72), so a packed store whose cones qualify
+ * builds the lite slots of ALL its instances once (slot i of `dst` from slot i of `src`, dst->n >= src->n) and then
+ * serves batches of ids through the solve half of cave_hip_cone_step (no pack half).  status [src->n] or NULL:
+ * CAVE_ST_OK, or CAVE_ST_TOO_LARGE for a cone the one-wave solver does not take (its slot is marked so). */
+int32_t cave_hip_lite_from_packed(const cave_cone_store* src, const cave_lite_store* dst, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

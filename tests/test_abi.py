@@ -68,9 +68,10 @@ def test_default_limits_and_arg_validation():
     assert 0 < lib.cave_hip_step_lds_bytes(60, 40) <= step
     assert lib.cave_hip_step_lds_bytes(235, 300) < 0 and lib.cave_hip_step_lds_bytes(40000, 190) < 0
     none7 = [None] * 7
-    assert lib.cave_hip_cone_step(None, None, 0, 0, 1.0, 0.0, 0, *none7, None, 0, 0, 190, None, None, None, None) == 0  # nothing to do
-    assert lib.cave_hip_cone_step(None, None, 4, 2, 1.0, 0.2, 0, *none7, None, 0, 0, 190, None, None, None, None) == -1
+    assert lib.cave_hip_cone_step(None, None, None, 0, 0, 1.0, 0.0, 0, 0, *none7, None, 0, 0, 190, None, None, None, None) == 0  # nothing to do
+    assert lib.cave_hip_cone_step(None, None, None, 4, 2, 1.0, 0.2, 0, 0, *none7, None, 0, 0, 190, None, None, None, None) == -1
     assert b"cu_tickets" in lib.cave_hip_last_error()
+    assert lib.cave_hip_lite_from_packed(None, None, None, None) == -1
 
 
 def test_status_codes_match_header():

@@ -227,8 +227,9 @@ def test_modules_autograd_reduction_and_branching(golden):
     assert np.abs(t.cpu().numpy() - g["generic_min_exact_target"]).max() <= 4e-6
 
 
-def test_lazy_status_check_raises_one_call_later():
-    """solver_kwargs={'check': 'lazy'}: no host sync per step, the verdict of a launch arrives with the next call."""
+def test_lazy_status_check_raises_a_call_later():
+    """solver_kwargs={'check': 'lazy'}: no host sync per step; the verdict of a launch is examined by a later call, once
+    its copy has arrived (a later call never waits for it unless more than LAZY_MAX_PENDING are outstanding)."""
     import torch
 
     from cave_amd import synth
@@ -251,8 +252,9 @@ def test_lazy_status_check_raises_one_call_later():
     bad = torch.tensor(costs, device="cuda")
     bad[3, 5] = float("nan")
     lazy(bad, batch)                                  # launches; its status is only queued
+    torch.cuda.synchronize()                          # (the verdict has arrived on the host by now)
     with pytest.raises(ValueError):
-        lazy(good, batch)                             # ... and examined here
+        lazy(good, batch)                             # ... and is examined here
     flush_checks()
     with pytest.raises(ValueError):
         strict(bad, batch)                            # the strict mode raises at once

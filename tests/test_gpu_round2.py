@@ -187,6 +187,7 @@ def test_lazy_check_with_mixed_cone_sizes_under_one_shape():
     l1 = mod(p, torch.tensor(big, device="cuda"))            # lazy launch with the cached 4-wave shape: does not fit
     l1.sum().backward()
     assert torch.isfinite(l1).all() and torch.isfinite(p.grad).all()   # masked, not NaN
+    torch.cuda.synchronize()
     with pytest.raises(HipSolverError):
         mod(p, torch.tensor(small, device="cuda"))           # the verdict arrives here ...
     assert (m, d) not in qpsolver._settled and (m, d) not in qpsolver._wide_ok  # ... and the shape is forgotten

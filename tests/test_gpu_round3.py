@@ -137,7 +137,7 @@ def test_prefetch_wraps_a_loader_and_keeps_the_loop_body():
             loss = cave(reg(xb), bctr)
             reg.zero_grad()
             loss.backward()
-            out.append((float(loss), reg.weight.grad.clone()))
+            out.append((float(loss.detach()), reg.weight.grad.clone()))
         return out, kinds
 
     plain, _ = run(data)
@@ -151,6 +151,52 @@ def test_prefetch_wraps_a_loader_and_keeps_the_loop_body():
     for (l0, g0), (l1, g1) in zip(ref, skipped):
         assert abs(l0 - l1) <= 1e-6 and float((g0 - g1).abs().max()) <= 1e-6
     assert list(prefetch([])) == []
+
+
+_RCCL_SCRIPT = r"""
+import json, os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "tests")]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str({port}), RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+# the process group FIRST, before any other GPU call of this process (what an N-GPU rank does)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
+import numpy as np
+from cave_amd import synth
+from cave_amd.cave import EPO, innerConeAlignedCosine
+from cave_amd.dataset import ConeStore
+from cave_amd.dist import global_mean_loss, same_branch_seed, allreduce_grads_sum
+class M: modelSense = EPO.MINIMIZE
+ctrs, costs, _ = synth.tsp_batch(12, 48, seed=2)
+seed = same_branch_seed(4321)
+assert seed == 4321
+pred = torch.tensor(costs, device="cuda", requires_grad=True)
+c = torch.tensor(ctrs, device="cuda")
+mod = innerConeAlignedCosine(M(), solver="hip", seed=seed, reduction="none")
+per = mod(pred, c)
+g = global_mean_loss(per)            # the [sum loss, count] all-reduce over RCCL
+g.backward()
+grad_dist = pred.grad.clone()
+pred.grad = None
+mod2 = innerConeAlignedCosine(M(), solver="hip", seed=seed, reduction="mean")
+l2 = mod2(pred, c)
+l2.backward()
+red = torch.stack([per.detach().sum(), torch.tensor(float(per.numel()), device="cuda")])
+dist.all_reduce(red)
+lin = torch.nn.Linear(3, 5).cuda()
+lin(torch.ones(2, 3, device="cuda")).sum().backward()
+w0 = lin.weight.grad.clone()
+allreduce_grads_sum(lin.parameters())
+ragged = [torch.from_numpy(x[np.abs(x).sum(axis=1) > 0]) for x in ctrs]
+store = ConeStore.from_ragged_shard(ragged, 0, 1)
+o = store.cone_op(torch.arange(store.n, device="cuda"), pred.detach(), 2, -1.0, 0.2, outputs=("loss",))
+dist.barrier()
+out = dict(loss_dist=float(g), loss_plain=float(l2), grad_diff=float((grad_dist - pred.grad).abs().max()),
+           red=[float(red[0]), float(red[1])], wdiff=float((w0 - lin.weight.grad).abs().max()),
+           shard_n=store.n, shard_loss=float(o["loss"].mean()), backend=dist.get_backend())
+dist.destroy_process_group()
+print("RCCL_RESULT " + json.dumps(out))
+"""
 
 
 def _free_port():
