@@ -25,7 +25,7 @@ _UNITS = ["cave_hip"] + [f"k_{op}_w{w}" for op in ("dense", "pack", "packed") fo
     ["k_large_dense", "k_large_pack", "k_large_packed_w1", "k_large_packed_w2", "k_large_packed_w4", "k_step"]
 _SOURCES = [os.path.join(_CSRC, u + ".hip") for u in _UNITS] + _HEADERS
 _OBJ_DIR = os.path.join(_CSRC, "build")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 # status / mode constants (include/cave_hip.h)
 ST_OK, ST_NOT_CONVERGED, ST_TOO_LARGE, ST_BAD_INPUT = 0, 1, 2, 3

@@ -487,8 +487,18 @@ constexpr int kBandWaveDuos = 5;   // duos per lane
 constexpr int kBandWaveRegs = 20;  // prefetch registers per lane (factor rows of the back substitution)
 
 constexpr int kBandGroup = 32;     // rows built per call of the row producer
-constexpr int kBandSpinLimit = 1 << 22;  // polls before a wave stops waiting for the other one (never reached: an exit
-                                         // every wave takes even if the hand-over protocol were broken)
+// Polls before a wave stops waiting for the other one.  Never reached in a working hand-over; if it is (a broken or
+// starved protocol), the wave sets the instance's FAILURE WORD (word 4 of the flag area) and goes on, so that every wave
+// still reaches its exit; the caller turns the word into CAVE_ST_NOT_CONVERGED (solve_and_finish) -- a wave that fell
+// through has computed on rows the other wave had not delivered.  (Test builds shrink the limit and withhold a flag:
+// tests/test_simt_emul.py.)
+#ifndef CAVE_BAND_SPIN_LIMIT
+#define CAVE_BAND_SPIN_LIMIT (1 << 22)
+#endif
+constexpr int kBandSpinLimit = CAVE_BAND_SPIN_LIMIT;
+// The flag words are relaxed atomic LDS accesses ordered by compiler barriers only (CAVE_FLAG_LOAD / CAVE_FLAG_STORE +
+// CAVE_WAVE_ORDER): valid because a wave's LDS operations execute in issue order and the two waves share one LDS --
+// i.e. NOT in threadgroup-split mode (tgsplit), which these kernels are never compiled for.
 
 CAVE_HOSTDEV int band_wave_duos(int bw) {
   int nd = 0;
@@ -521,7 +531,7 @@ CAVE_HOSTDEV uint32_t band_wave_flags_at(int bw) {  // (behind the row ring and 
   return a > b ? a : b;
 }
 CAVE_HOSTDEV uint32_t band_wave_region(int bw, int p) {
-  return band_wave_flags_at(bw) + 2u + ((uint32_t)p < band_wave_scratch(bw) ? band_wave_scratch(bw) : 0u);
+  return band_wave_flags_at(bw) + 3u + ((uint32_t)p < band_wave_scratch(bw) ? band_wave_scratch(bw) : 0u);  // (3 doubles: four flag words + the failure word)
 }
 
 #if defined(CAVE_GPU_CODE)
@@ -700,7 +710,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   // Component-major: the lanes of a duo round read consecutive t, i.e. consecutive words (as [t][a] records the
   // same reads were 16-way bank conflicts: rocprof counted 1.0e9 conflict cycles per launch on the 30x30 batch)
   const int ncol = bw + NB + 2;
-  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 2);
+  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 3);
   auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;
@@ -757,25 +767,33 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       for (int g = 0; g < p_end; g += G) {
         const int need = g + G - RING;  // rows [g, g + G) take the slots of rows [g - RING, g + G - RING)
         if (need > 0) {
-          for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+          int spin = 0;
+          for (; spin < kBandSpinLimit; ++spin) {
             if (__builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 1)) >= need) break;
             CAVE_SPIN_PAUSE();
           }
+          if (spin >= kBandSpinLimit && lane == 0) CAVE_FLAG_STORE(flags + 4, 1);  // hand-over failed: flag the instance
           CAVE_WAVE_ORDER();
         }
         produce(g, slot);
         CAVE_LDS_WAIT();
         slot += G;
         slot = slot >= RING ? 0 : slot;
+#ifdef CAVE_TEST_WITHHOLD_FLAG  // (test builds: the producer "forgets" to announce one group of rows)
+        if (lane == 0 && g != CAVE_TEST_WITHHOLD_FLAG * G) CAVE_FLAG_STORE(flags + 0, g + G);
+#else
         if (lane == 0) CAVE_FLAG_STORE(flags + 0, g + G);
+#endif
       }
       // ---- then the factor rows of the back substitution, top row first, into the 64-row ring (row r: slot r & 63).
       // Two batches of BR rows in registers (lane = entry): the loads of one are in flight while the other waits
       // for its slots -- row r may take the slot of row r + 64 once the substitution has passed that row.
-      for (int spin = 0; spin < kBandSpinLimit; ++spin) {  // the eliminator's stores have completed (its fence)
+      int spin = 0;
+      for (; spin < kBandSpinLimit; ++spin) {  // the eliminator's stores have completed (its fence)
         if (__builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 2)) <= p) break;
         CAVE_SPIN_PAUSE();
       }
+      if (spin >= kBandSpinLimit && lane == 0) CAVE_FLAG_STORE(flags + 4, 1);  // hand-over failed: flag the instance
       CAVE_WAVE_ORDER();
       constexpr int BR = 16;
       const int rs = band_wave_ring_stride(bw);
@@ -787,10 +805,12 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       };
       auto storeb = [&](const double* rg, const int top) __attribute__((always_inline)) {
         const int lowest = top - (BR - 1) > 0 ? top - (BR - 1) : 0;
-        for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+        int spin = 0;
+        for (; spin < kBandSpinLimit; ++spin) {
           if (__builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 3)) < lowest + 64) break;
           CAVE_SPIN_PAUSE();
         }
+        if (spin >= kBandSpinLimit && lane == 0) CAVE_FLAG_STORE(flags + 4, 1);  // hand-over failed: flag the instance
         CAVE_WAVE_ORDER();
         if (lane < ld) {
 #pragma unroll
@@ -856,11 +876,13 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
       // rows k .. k + R - 1 are resident before the step touches them
       if constexpr (DUO) {
         if (have < k + R) {
-          for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+          int spin = 0;
+          for (; spin < kBandSpinLimit; ++spin) {
             have = __builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 0));
             if (have >= k + R) break;
             CAVE_SPIN_PAUSE();
           }
+          if (spin >= kBandSpinLimit && lane == 0) CAVE_FLAG_STORE(flags + 4, 1);  // hand-over failed: flag the instance
           CAVE_WAVE_ORDER();
         }
       } else {
@@ -1038,11 +1060,13 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
         if (lane == 0) CAVE_FLAG_STORE(flags + 3, k);  // rows above k are done with: their slots are free
         const int need = k - bw - NB > 0 ? k - bw - NB : 0;
         if (chi_next > need) {
-          for (int spin = 0; spin < kBandSpinLimit; ++spin) {
+          int spin = 0;
+          for (; spin < kBandSpinLimit; ++spin) {
             chi_next = __builtin_amdgcn_readfirstlane(CAVE_FLAG_LOAD(flags + 2));
             if (chi_next <= need) break;
             CAVE_SPIN_PAUSE();
           }
+          if (spin >= kBandSpinLimit && lane == 0) CAVE_FLAG_STORE(flags + 4, 1);  // hand-over failed: flag the instance
           CAVE_WAVE_ORDER();
         }
       } else {

@@ -288,6 +288,8 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.band_hot = hot && hot->owns(w.bwin) && hot->owns(w.bz) && hot->owns(w.step) && hot->owns(w.act) &&
                    hot->owns(w.bstg);
       w.band_wave = wave_mode && w.band_hot;
+      // failure word of the two-wave hand-over (cone_band.h kBandSpinLimit): cleared here, examined after the solver
+      if (w.band_wave && c.tid() == 0) reinterpret_cast<int*>(w.bwin + band_wave_flags_at(bw))[4] = 0;
 #ifdef CAVE_EMUL_COUNTERS
       if (c.tid() == 0 && w.band_wave) ++emul_counters()[1];
 #endif
@@ -327,6 +329,20 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.dn.on = false;
       w.gen.on = false;
       if (p > C::PMAX) return ST_TOO_LARGE;
+      w.hscale = 1.0;
+      w.hinv = 1.0;
+      if constexpr (C::NWAVES > 1) {  // fixed-point scale of the multi-wave Hessian sums: |H_ab| <= (largest entry)^2 * (longest row)
+        double vm = v.pm1 ? 1.0 : 0.0, ml = 1.0;
+        if (!v.pm1) {
+          const uint32_t nz = v.mptr[p];
+          for (uint32_t e = c.tid(); e < nz; e += (uint32_t)C::NT) vm = fmax(vm, fabs((double)v.mval[e]));
+        }
+        for (int i = c.tid(); i < p; i += C::NT) ml = fmax(ml, (double)(v.mptr[i + 1] - v.mptr[i]));
+        vm = c.reduce_max(vm);
+        ml = c.reduce_max(ml);
+        w.hscale = fixed_scale(vm, vm * ml);
+        w.hinv = 1.0 / w.hscale;
+      }
       // rc[d], theta[32] and dv[32] are the always-zero dummies of the lite index structures (cone_core.h)
       const uint32_t pg = pp < 33u ? 33u : pp;
       w.rc = ar.get<double>((uint32_t)d + 1u);
@@ -432,6 +448,18 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     st = r.status;
     f = r.f;
     *iters_out = r.iters;
+#if defined(CAVE_GPU_CODE)
+    if constexpr (LARGE) {
+      if (w.band_wave) {  // a wave gave up waiting for the other one: its rows were not the delivered ones
+        c.sync();
+        if (reinterpret_cast<const int*>(w.bwin + band_wave_flags_at(w.bw))[4] != 0) {
+          if (warm_state && c.tid() == 0) *warm_state = 0;
+          fill_failure(c, d, b, o);  // (nothing computed from undelivered rows leaves the kernel)
+          return ST_NOT_CONVERGED;
+        }
+      }
+    }
+#endif
     if (warm_theta && warm_state) {  // keep the multipliers for the next solve of this cone
       if (st == ST_OK) for (int i = c.tid(); i < p; i += C::NT) warm_theta[i] = (float)w.theta[i];
       if (c.tid() == 0) *warm_state = (uint8_t)(st == ST_OK ? 1 : 0);

@@ -213,14 +213,15 @@ _SIMT_DEPS = _DEPS + [_SIMT_SRC, os.path.join(_HERE, "emul", "simt", "hip", "hip
     os.path.join(_HERE, "..", "cave_amd", "csrc", n) for n in ("wave_prims.h", "ctx_wave.h", "ctx_block.h")]
 
 
-def build_simt(asan: bool = False) -> str:
-    out = os.path.join(_HERE, "emul", "_simt_asan.so" if asan else "_simt.so")
+def build_simt(asan: bool = False, defines: tuple = (), tag: str = "") -> str:
+    """`defines` / `tag`: a variant build (e.g. a tiny spin limit + a withheld hand-over flag) under its own name."""
+    out = os.path.join(_HERE, "emul", f"_simt{tag}_asan.so" if asan else f"_simt{tag}.so")
     newest = max(os.path.getmtime(p) for p in _SIMT_DEPS)
     if os.path.exists(out) and os.path.getmtime(out) >= newest:
         return out
     flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if asan else ["-O2"]
-    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-w", *flags, "-I" + os.path.join(_HERE, "emul", "simt"), _SIMT_SRC,
-           "-o", out]
+    cmd = ["g++", "-std=c++17", "-fPIC", "-shared", "-w", *flags, *["-D" + x for x in defines],
+           "-I" + os.path.join(_HERE, "emul", "simt"), _SIMT_SRC, "-o", out]
     subprocess.run(cmd, check=True)
     return out
 
@@ -230,8 +231,8 @@ class Simt:
     Stores come from Emul.pack / Emul.pack_large (host arrays).  `seed` != 0 shuffles the order in which the lanes
     run between two rendezvous (a hand-over the source does not order then shows up as wrong numbers)."""
 
-    def __init__(self, asan: bool = False):
-        self.lib = C.CDLL(build_simt(asan))
+    def __init__(self, asan: bool = False, defines: tuple = (), tag: str = ""):
+        self.lib = C.CDLL(build_simt(asan, defines, tag))
         self.lib.cave_simt_packed_large_slice_bytes.restype = C.c_int64
 
     def path_counters(self):

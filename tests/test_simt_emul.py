@@ -113,6 +113,29 @@ def test_band_elimination_under_emulation(emul, simt, golden, waves):
     assert simt.path_counters()[1] == 4  # the one-wave band form ran for every instance
 
 
+def test_band_hand_over_failure_is_reported(emul):
+    """cone_band.h kBandSpinLimit (VERDICT r3 / ADVICE r3): the producer / eliminator waves of the band elimination meet
+    through LDS words and every wait is bounded; a wait that runs out used to fall through silently -- the wave then
+    computed on rows the other one had not delivered and the instance still reported CAVE_ST_OK.  A variant build
+    withholds ONE "rows built" announcement of the producer and shrinks the limit: the eliminator's wait runs out, every
+    wave still reaches its exit, and the instance reports CAVE_ST_NOT_CONVERGED with NaN outputs.  The same build with
+    the announcement in place (one-wave shape: no hand-over) stays correct."""
+    from emul_lib import Simt
+    from cave_amd import synth
+
+    c, y, _ = synth.sp_batch(12, 12, 2, seed=0)
+    st, arrs, mr, _ = emul.pack_large(c)
+    bw = store_bandwidth(arrs, 2, c.shape[2])
+    broken = Simt(defines=("CAVE_BAND_SPIN_LIMIT=4000", "CAVE_TEST_WITHHOLD_FLAG=2"), tag="_withhold")
+    broken.path_counters()
+    o = broken.cone_packed_large(st, arrs, mr, bw, np.arange(2), y, MODE_PROJECT, sign=-1.0, waves=2)
+    assert broken.path_counters()[1] == 2                 # the two-wave band form ran
+    assert (o["status"] == 1).all(), o["status"]           # CAVE_ST_NOT_CONVERGED, not a silent CAVE_ST_OK
+    assert np.isnan(o["proj"]).all() and np.isnan(o["rnorm"]).all()
+    ok = broken.cone_packed_large(st, arrs, mr, bw, np.arange(2), y, MODE_PROJECT, sign=-1.0, waves=1)
+    assert (ok["status"] == 0).all()                       # no producer wave, nothing withheld
+
+
 @pytest.mark.parametrize("m,width,pairs", [(70, 5, 0), (90, 8, 5), (60, 14, 0)])
 def test_band_elimination_with_bound_rows_under_emulation(emul, simt, m, width, pairs):
     """Banded INEQUALITY cones (half bandwidths 4 / 7 / 13): rows are held at their bound by the active-set loop, so

@@ -9,5 +9,5 @@ ALL="k_dense_w1 k_dense_w2 k_dense_w4 k_dense_w8 k_pack_w1 k_pack_w2 k_pack_w4 k
 U=tools/diag/_unity_stamps.hip
 : > "$U"
 for u in cave_hip $ALL; do echo "#include \"../../cave_amd/csrc/$u.hip\"" >> "$U"; done
-hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -std=c++17 -fPIC -shared -DCAVE_STAMPS ${EXTRA_FLAGS} "$U" \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DCAVE_STAMPS ${EXTRA_FLAGS} "$U" \
   -o "${OUT:-tools/diag/libcave_hip_stamps.so}"
