@@ -197,25 +197,20 @@ def workspace(device, nbytes: int):
     return t
 
 
-_slot_cache: dict = {}
-
-
 def large_slots(device, B: int, slice_bytes: int) -> int:
     """Workgroups (= workspace slices) for a large-cone launch: 4 per CU, bounded by free memory.
-    The free-memory query is a blocking driver call (~5 ms: more than a TSP-100 batch takes), so the answer is kept
-    per (device, slice size) and only asked again when a bigger workspace than the one held would be needed."""
+    The free-memory query is a blocking driver call (~5 ms: more than a TSP-100 batch takes), so it is only made when
+    the workspace HAS TO GROW (a rare path) -- and then always: a figure remembered from an earlier, emptier device
+    would let a later, larger request run into an out-of-memory error."""
     import torch
 
     want = int(max(1, min(B, 1024)))
     held = _workspaces[device].numel() if device in _workspaces else 0
     if want * slice_bytes <= held:
         return want
-    key = (device, int(slice_bytes))
-    cap = _slot_cache.get(key)
-    if cap is None or cap < want:
-        free, _ = torch.cuda.mem_get_info(device)
-        budget = min((free + held) // 2, 64 << 30)
-        cap = _slot_cache[key] = int(max(1, min(1024, budget // max(slice_bytes, 1))))
+    free, _ = torch.cuda.mem_get_info(device)
+    budget = min((free + held) // 2, 64 << 30)
+    cap = int(max(1, min(1024, budget // max(slice_bytes, 1))))
     return int(max(1, min(want, cap)))
 
 
