@@ -144,7 +144,8 @@ int32_t cave_hip_pack_fill(const float* ctrs, int64_t B, int64_t m_max, int64_t 
 
 int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1) {
   if (d <= 0 || max_rows < 0 || max_nnz < 0) return CAVE_E_INVALID;
-  int32_t s = packed_lds_bytes(d, max_rows, max_nnz, all_pm1 != 0, all_pm1 != 2);
+  int32_t s = all_pm1 == 3 ? packed_lds_bytes(d, max_rows, max_nnz, true, false, true)
+                           : packed_lds_bytes(d, max_rows, max_nnz, all_pm1 != 0, all_pm1 != 2);
   return s < 0 ? CAVE_E_INVALID : s;
 }
 

@@ -185,7 +185,15 @@ struct SolveView {
   const uint8_t* usign;   // [d]  bit0: +e_k row present, bit1: -e_k row present
   int nlong;              // reduced rows with more than kLongRow entries ...
   const uint32_t* longrow;  // ... and their indices
+  bool csc_far = false;   // "diet" layout (TSP-50 class: cone_instance.h run_packed_instance): cvar points into the packed
+                          // store (global memory, signs in bit 15), read with batched loads; cptr stays in LDS
 };
+
+// packed lower triangle: H(i, j), j <= i, at i (i + 1) / 2 + j
+CAVE_HD uint32_t tri_idx(uint32_t i, uint32_t j) {
+  const uint32_t a = i > j ? i : j, b = i > j ? j : i;
+  return a * (a + 1u) / 2u + b;
+}
 
 // Rows of H = M W M^T made on demand (one-wave band elimination of cones WITHOUT bound rows: grid shortest path).
 // The band is then never materialised: no zeroing, no atomics, no 8 p (bw + 1) bytes written and read back per
@@ -238,6 +246,7 @@ struct SolveWork {
   double* g2;      // [p]  right-hand side / H*step scratch
   double* step;    // [p]  Newton step of one inner round
   double* H;       // [p*ldh]  dense rows, or (band form) H[j*ldh + t] = H(j+t, j), t = 0..bw, ldh = bw+1
+  bool tri = false;  // LDS-path general solver, diet layout: H is the packed lower triangle (tri_idx), p (p + 1) / 2 entries
   uint8_t* act;    // [p]
   float* wold;     // [d]  weight each coordinate currently has in H (fast path; the band path rebuilds H)
   const float* warm;  // [p] multipliers of an earlier solve of this cone (global memory), or null: starting point

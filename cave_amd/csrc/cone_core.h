@@ -940,6 +940,10 @@ CAVE_HD void band_hessian(C& c, const SolveView& v, SolveWork& w, bool in_lds, W
   }
 }
 
+// does the context carry the diet layout of the packed operator (BlockCtx<4, true>)?
+template <class C, class = void> struct ctx_diet : std::false_type {};
+template <class C> struct ctx_diet<C, std::void_t<decltype(C::DIET_OK)>> : std::bool_constant<C::DIET_OK> {};
+
 // does the context carry the lite index structures (SoloCtx)?
 template <class C, class = void> struct ctx_lite : std::false_type {};
 template <class C> struct ctx_lite<C, std::void_t<decltype(C::LITE)>> : std::bool_constant<C::LITE> {};
@@ -1134,7 +1138,12 @@ CAVE_HD void gather_any(C& c, const SolveView& v, const float* base, const doubl
   if constexpr (ctx_lite<C>::value) { lite_gather(c, c.lite, v.d, base, th, sgn, out); return; }
 #endif
   if constexpr (STREAMED && C::WL > 1) gather_mt_streamed<C, PM1>(c, v, base, th, sgn, out);
-  else gather_mt<C, PM1>(c, v, base, th, sgn, out);
+  else {
+    if constexpr (ctx_diet<C>::value && PM1) {
+      if (v.csc_far) { gather_mt_streamed<C, PM1>(c, v, base, th, sgn, out); return; }  // CSC in the store: batched loads
+    }
+    gather_mt<C, PM1>(c, v, base, th, sgn, out);
+  }
 }
 
 // One Newton step = exact minimisation of the local quadratic model over the
@@ -1233,7 +1242,10 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   if constexpr (BAND) dense_on = w.dn.on;
   bool hgen_on = false;
   if constexpr (BAND) hgen_on = w.gen.on;
-  if (!dense_on && !hgen_on) for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = 0.0;
+  bool tri = false;  // diet layout: H is the packed lower triangle
+  if constexpr (ctx_diet<C>::value && !BAND) tri = w.tri;
+  const int hsize = tri ? p * (p + 1) / 2 : p * ldh;
+  if (!dense_on && !hgen_on) for (int idx = c.tid(); idx < hsize; idx += NT) w.H[idx] = 0.0;
   if constexpr (!BAND) for (int k = c.tid(); k < d; k += NT) w.wold[k] = 0.f;
   c.sync();
   double reg_rel = 1e-12;  // Levenberg shift relative to max diag(H); raised when a step stalls
@@ -1354,24 +1366,93 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       const double hsc = w.hscale, hiv = w.hinv;
       auto Hq = reinterpret_cast<typename SpacePtr<long long, 3>::type>(space_cast<3>(w.H));
       if constexpr (FIXED) {
-        for (int idx = c.tid(); idx < p * ldh; idx += NT) Hq[idx] = (long long)llrint(w.H[idx] * hsc);
+        for (int idx = c.tid(); idx < hsize; idx += NT) Hq[idx] = (long long)llrint(w.H[idx] * hsc);
         c.sync();
       }
       auto hadd = [&](uint32_t idx, double x) {
         if constexpr (FIXED) c.atomic_add_i64_lds(Hq + idx, (long long)llrint(x * hsc));
         else c.atomic_add_f64(&w.H[idx], x);
       };
-      for (int k = c.tid(); k < d; k += NT) {
+      auto new_weight = [&](int k) -> float {
         const uint8_t u = v.usign[k];
-        float wn;
-        if (u == 0) wn = 1.0f;
-        else if (u == 3) wn = 0.0f;
-        else {
-          const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
-          const float z = (float)(t * inv_mu);  // the weight is a heuristic, quantised anyway: float is plenty
-          if (mu > 0.0 && fabsf(z) < 4.0f) wn = floorf(8.0f * (1.0f + z / sqrtf(1.0f + z * z)) + 0.5f) * (1.0f / 16.0f);
-          else wn = t > 0.0 ? 1.0f : 0.0f;
+        if (u == 0) return 1.0f;
+        if (u == 3) return 0.0f;
+        const double t = (u == 2) ? r[k] : -r[k];  // > 0 on the side that carries residual
+        const float z = (float)(t * inv_mu);  // the weight is a heuristic, quantised anyway: float is plenty
+        if (mu > 0.0 && fabsf(z) < 4.0f) return floorf(8.0f * (1.0f + z / sqrtf(1.0f + z * z)) + 0.5f) * (1.0f / 16.0f);
+        return t > 0.0 ? 1.0f : 0.0f;
+      };
+      bool far_done = false;
+#if defined(CAVE_GPU_CODE)
+      if constexpr (ctx_diet<C>::value && PM1) {
+        if (v.csc_far) {
+          // diet layout: the columns are read from the packed store (global memory).  G coordinates per thread at a
+          // time, the first E entries of each requested before any is used (one memory round trip per pass; a TSP
+          // column holds its two degree rows + the cuts through the edge: <= 7), the packed triangle of H.
+          constexpr int G = 4, E = 8;
+          const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
+          for (int k0 = c.tid(); k0 < d; k0 += G * NT) {
+            uint32_t lo[G], cnt[G], ent[G][E];
+            double dwv[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+              const int k = k0 + u * NT;
+              lo[u] = 0; cnt[u] = 0; dwv[u] = 0.0;
+              if (k < d) {
+                const float wn = new_weight(k), wo = w.wold[k];
+                if (wn != wo) {
+                  w.wold[k] = wn;
+                  dwv[u] = (double)wn - (double)wo;
+                  lo[u] = v.cptr[k];
+                  cnt[u] = v.cptr[k + 1] - lo[u];
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const uint32_t ee = lo[u] + (uint32_t)e < last ? lo[u] + (uint32_t)e : last;  // clamped, unconditional
+                ent[u][e] = v.cvar[ee];
+              }
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+              if (cnt[u] == 0u) continue;
+              const double dw = dwv[u];
+              auto pair = [&](uint32_t x1, uint32_t x2) {  // H(a, b) += dw s1 s2, a > b (columns are sorted by row)
+                const uint32_t a = x1 & 0x7fffu, b = x2 & 0x7fffu;
+                const double vv = ((x1 ^ x2) & 0x8000u) ? -dw : dw;
+                if (tri) hadd(tri_idx(a, b), vv);
+                else { hadd(a * (uint32_t)ldh + b, vv); hadd(b * (uint32_t)ldh + a, vv); }
+              };
+              auto diag = [&](uint32_t x1) {
+                const uint32_t a = x1 & 0x7fffu;
+                hadd(tri ? tri_idx(a, a) : a * (uint32_t)ldh + a, dw);
+              };
+              if (cnt[u] <= (uint32_t)E) {  // the prefetched entries, statically indexed (registers)
+                static_for<0, E>([&](auto e1c) {
+                  constexpr int e1 = decltype(e1c)::value;
+                  if ((uint32_t)e1 < cnt[u]) {
+                    diag(ent[u][e1]);
+                    static_for<0, e1>([&](auto e2c) { pair(ent[u][e1], ent[u][decltype(e2c)::value]); });
+                  }
+                });
+              } else {  // a column longer than the prefetch (an edge inside more than six cuts): entry by entry
+                for (uint32_t e1 = 0; e1 < cnt[u]; ++e1) {
+                  const uint32_t x1 = v.cvar[lo[u] + e1];
+                  diag(x1);
+                  for (uint32_t e2 = 0; e2 < e1; ++e2) pair(x1, v.cvar[lo[u] + e2]);
+                }
+              }
+            }
+          }
+          far_done = true;
         }
+      }
+#endif
+      if (!far_done)
+      for (int k = c.tid(); k < d; k += NT) {
+        const float wn = new_weight(k);
         const float wo = w.wold[k];
         if (wn == wo) continue;
         w.wold[k] = wn;
@@ -1382,18 +1463,18 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           double v1, v2;
           csc_entry<PM1>(v, e1, a, v1);
           const double va = dw * v1;
-          hadd(a * ldh + a, va * v1);
+          hadd(tri ? tri_idx(a, a) : a * (uint32_t)ldh + a, va * v1);
           for (uint32_t e2 = lo; e2 < e1; ++e2) {
             csc_entry<PM1>(v, e2, b, v2);
             double vv = va * v2;
-            hadd(a * ldh + b, vv);
-            hadd(b * ldh + a, vv);
+            if (tri) hadd(tri_idx(a, b), vv);
+            else { hadd(a * (uint32_t)ldh + b, vv); hadd(b * (uint32_t)ldh + a, vv); }
           }
         }
       }
       if constexpr (FIXED) {
         c.sync();
-        for (int idx = c.tid(); idx < p * ldh; idx += NT) w.H[idx] = (double)Hq[idx] * hiv;
+        for (int idx = c.tid(); idx < hsize; idx += NT) w.H[idx] = (double)Hq[idx] * hiv;
       }
       }
     }
@@ -1453,7 +1534,13 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           else
             solve_spd_band<C, false>(c, w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step, w.bstg, w.bch);
         }
-        else c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
+        else {
+          bool solved = false;
+          if constexpr (ctx_diet<C>::value) {
+            if (tri) { c.solve_spd_tri(w.H, rhs, w.act, p, reg_rel, w.step); solved = true; }
+          }
+          if (!solved) c.solve_spd(w.H, ldh, rhs, w.act, p, reg_rel, w.step);
+        }
         c.sync();
         CAVE_ACC(5);
         // ratio test to the first blocking bound
@@ -1479,6 +1566,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
               if constexpr (ctx_lite<C>::value) {  // lower triangle only
                 for (int j = 0; j <= i; ++j) s += w.H[i * ldh + j] * w.step[j];
                 for (int j = i + 1; j < p; ++j) s += w.H[j * ldh + i] * w.step[j];
+              } else if (tri) {
+                for (int j = 0; j < p; ++j) s += w.H[tri_idx((uint32_t)i, (uint32_t)j)] * w.step[j];
               } else {
                 for (int j = 0; j < p; ++j) s += w.H[i * ldh + j] * w.step[j];
               }

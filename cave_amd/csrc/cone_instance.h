@@ -8,6 +8,8 @@
 
 namespace cave {
 
+CAVE_HOSTDEV int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1, bool lite_room, bool diet);
+
 struct OutPtrs {
   float* proj;
   float* rnorm;
@@ -355,7 +357,9 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       w.g2 = ar.get<double>(pp);
       w.step = ar.get<double>(pp);
       w.ldh = p | 1;
-      w.H = ar.get<double>((uint32_t)(p > 0 ? p * w.ldh : 1));
+      w.tri = false;
+      if constexpr (ctx_diet<C>::value) w.tri = v.csc_far;  // diet layout: H as the packed lower triangle
+      w.H = ar.get<double>((uint32_t)(p > 0 ? (w.tri ? p * (p + 1) / 2 : p * w.ldh) : 1));
       w.act = ar.get<uint8_t>(pp);
     }
     w.res = res;
@@ -604,15 +608,23 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
     const uint32_t nz = S.n_nnz ? (uint32_t)S.n_nnz[slot] : (uint32_t)(S.nnz_off[slot + 1] - z0);
     const bool need_avg = (P.mode == MODE_INNER || P.mode == MODE_HEURISTIC || P.mode == MODE_AVG);
     const bool need_proj = (P.mode == MODE_PROJECT || P.mode == MODE_EXACT || P.mode == MODE_INNER || P.mode == MODE_IPM);
+    const bool pm1 = (S.flags[slot] & 1) != 0;
+    // Diet layout (contexts that carry it: the four-wave wide shape): taken by an instance whose ordinary arena does not
+    // fit this launch's LDS -- the host then launched with the diet figure of its largest cone to get two workgroups per
+    // compute unit (TSP-50: 107 KB -> 76 KB).  Needs the signs folded into the store's indices (flags bit 1).
+    bool diet = false;
+    if constexpr (ctx_diet<C>::value) {
+      diet = pm1 && (S.flags[slot] & 2) != 0 && P.mode != MODE_IPM && p > kLiteMaxRows &&
+             (uint32_t)packed_lds_bytes(d, p, (int32_t)nz, true, false, false) > P.lds_bytes;
+    }
     float* y = ar.get<float>(d);
-    float* avg = need_avg ? ar.get<float>(d) : nullptr;
+    float* avg = (need_avg && !diet) ? ar.get<float>(d) : nullptr;
     uint8_t* usign = ar.get<uint8_t>(d);
     uint32_t* cptr = ar.get<uint32_t>(d + 1);
-    const bool pm1 = (S.flags[slot] & 1) != 0;
     uint32_t* mptr = ar.get<uint32_t>((uint32_t)p + 1u);
     uint8_t* vkind = ar.get<uint8_t>(p > 0 ? p : 1);
     uint16_t* mcol = ar.get<uint16_t>(nz > 0 ? nz : 1);
-    uint16_t* cvar = ar.get<uint16_t>(nz > 0 ? nz : 1);
+    uint16_t* cvar = diet ? nullptr : ar.get<uint16_t>(nz > 0 ? nz : 1);
     float* mval = pm1 ? nullptr : ar.get<float>(nz > 0 ? nz : 1);
     float* cvalc = pm1 ? nullptr : ar.get<float>(nz > 0 ? nz : 1);
     if (ar.ovf) st = ST_TOO_LARGE;
@@ -621,6 +633,7 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
       // U rounds of operands before it stores any, so a 530-entry TSP-20 cone costs three memory round trips instead
       // of nine (measured: the load was 15 k of the one-wave kernel's 32 k cycles outside the Newton loop).
       constexpr int U = 4;
+      const bool stage_avg = need_avg && !diet;
       for (int k0 = c.tid(); k0 < d; k0 += U * NT) {
         float yv[U], av[U];
         uint8_t uv[U];
@@ -629,7 +642,7 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
           const int k = k0 + u * NT, kc = k < d ? k : d - 1;
           yv[u] = P.pred ? P.pred[b * d + kc] : 0.f;
           uv[u] = S.usign[slot * d + kc];
-          av[u] = need_avg ? S.avg[slot * d + kc] : 0.f;
+          av[u] = stage_avg ? S.avg[slot * d + kc] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -637,7 +650,7 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
           if (k < d) {
             y[k] = P.sign * yv[u];
             usign[k] = uv[u];
-            if (need_avg) avg[k] = av[u];
+            if (stage_avg) avg[k] = av[u];
           }
         }
       }
@@ -663,16 +676,17 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
             const uint32_t e = e0 + (uint32_t)(u * NT), ec = e < nz ? e : elast;  // clamped: loads are unconditional
             cc[u] = S.ccol[z0 + ec];
             cvl[u] = S.cval[z0 + ec];
-            cr[u] = S.cvar[z0 + ec];
-            crl[u] = S.cvalc[z0 + ec];
+            cr[u] = diet ? (uint16_t)0 : S.cvar[z0 + ec];
+            crl[u] = diet ? 0.f : S.cvalc[z0 + ec];
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const uint32_t e = e0 + (uint32_t)(u * NT);
             if (e < nz) {
               if (pm1) {
-                mcol[e] = (uint16_t)(cc[u] | (cvl[u] < 0.f ? 0x8000u : 0u));
-                cvar[e] = (uint16_t)(cr[u] | (crl[u] < 0.f ? 0x8000u : 0u));
+                // (stores of the large path / the diet tier carry the sign in bit 15 already: flags bit 1)
+                mcol[e] = (uint16_t)((cc[u] & 0x7fffu) | (cvl[u] < 0.f ? 0x8000u : 0u));
+                if (!diet) cvar[e] = (uint16_t)((cr[u] & 0x7fffu) | (crl[u] < 0.f ? 0x8000u : 0u));
               } else {
                 mcol[e] = cc[u];
                 mval[e] = cvl[u];
@@ -687,9 +701,11 @@ CAVE_HD void run_packed_instance(C& c, unsigned char* smem, const PackedParams& 
       SolveView v;
       v.d = d; v.p = p; v.n_valid = S.n_valid[slot]; v.pm1 = pm1;
       v.mptr = mptr; v.mcol = mcol; v.mval = mval; v.vkind = vkind;
-      v.cptr = cptr; v.cvar = cvar; v.cvalc = cvalc; v.usign = usign;
+      v.cptr = cptr; v.cvar = diet ? S.cvar + z0 : cvar; v.cvalc = cvalc; v.usign = usign;
       v.nlong = 0; v.longrow = nullptr;
-      st = solve_and_finish(c, ar, nullptr, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters,
+      v.csc_far = diet;
+      st = solve_and_finish(c, ar, nullptr, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y,
+                            (need_avg && diet) ? S.avg + slot * d : avg, b, P.o, &iters,
                             S.warm_theta ? S.warm_theta + r0 : nullptr, S.warm_state ? S.warm_state + slot : nullptr);
     }
   }
@@ -856,21 +872,29 @@ static inline uint32_t packed_large_lds_bytes(int64_t max_rows, int64_t max_bw) 
 }
 
 // lite_room: reserve the index structures of the one-wave lite solver (only launches of up to 2048 instances use it)
-static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false,
-                                       bool lite_room = true) {
+// diet: the layout for +-1 cones of the TSP-50 class (50 - 64 reduced rows, thousands of non-zeros: 100+ KB otherwise,
+// one workgroup per compute unit) -- H as a packed lower triangle, the CSC entries and the average normal read in
+// place from the packed store instead of staged: ~30 KB less, two workgroups per compute unit.
+CAVE_HOSTDEV int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1, bool lite_room, bool diet) {
   uint64_t s = 0;
   int64_t p = max_rows;
-  s += align8u(4 * d) * 2 + align8u(d) + align8u(4 * (d + 1));                          // y, avg, usign, cptr
-  s += align8u(4 * (p + 1)) + align8u(p);                                               // mptr, vkind
-  s += 2 * (align8u(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : align8u(4 * (int64_t)max_nnz)));  // CSR + CSC (+ values)
-  s += align8u(8 * d) * 3 + align8u(4 * d);                                              // res, tvec, rc, wold
-  s += 7 * align8u(8 * p) + align8u(8 * p * (p | 1)) + 2 * align8u(p) + align8u(4 * p) + 128 + 256 + 8 + 2 * 8 * 33;
-  if (lite_room && all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
+  const uint64_t a8 = 7u;
+  auto al = [&](uint64_t x) -> uint64_t { return (x + a8) & ~a8; };
+  s += al(4 * d) * (diet ? 1 : 2) + al(d) + al(4 * (d + 1));                              // y, (avg,) usign, cptr
+  s += al(4 * (p + 1)) + al(p);                                                           // mptr, vkind
+  s += (diet ? 1 : 2) * (al(2 * (int64_t)max_nnz) + (all_pm1 ? 0 : al(4 * (int64_t)max_nnz)));  // CSR (+ CSC) (+ values)
+  s += al(8 * d) * 3 + al(4 * d);                                                         // res, tvec, rc, wold
+  s += 7 * al(8 * p) + (diet ? al(8 * (p * (p + 1) / 2)) : al(8 * p * (p | 1))) + 2 * al(p) + al(4 * p) + 128 + 256 + 8 + 2 * 8 * 33;
+  if (lite_room && !diet && all_pm1 && p <= kLiteMaxRows && d <= kLiteMaxD) {  // lite index structures, if they fit (optional)
     const uint64_t with_lite = s + lite_lds_bytes((int)d, (uint32_t)max_nnz);
-    if (with_lite <= kMaxLds) s = with_lite;
+    if (with_lite <= 160u * 1024u) s = with_lite;
   }
-  if (s > kMaxLds) return -1;
+  if (s > 160u * 1024u) return -1;
   return (int32_t)s;
+}
+static inline int32_t packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, bool all_pm1 = false,
+                                       bool lite_room = true) {
+  return packed_lds_bytes(d, max_rows, max_nnz, all_pm1, lite_room, false);
 }
 
 }  // namespace cave

@@ -61,9 +61,12 @@ struct BlockCtx {
   static constexpr int TEAM = 4;
   static constexpr int SCAN_UNROLL = (NW <= 2 || WIDE) ? 8 : 4;  // KiB per wave per batch (two batches in flight); VGPR budget
   static constexpr int PMAX = (NW <= 2 || WIDE) ? 64 : 32;  // register budget: 128 VGPRs at 4 waves/SIMD, 256 at 2 (or WIDE)
-  static constexpr int MIN_WAVES_PER_EU = WIDE ? 1 : (NW <= 2 ? NW : 4);
+  static constexpr int MIN_WAVES_PER_EU = WIDE ? 2 : (NW <= 2 ? NW : 4);  // (WIDE: 256 registers -- two such workgroups share a compute unit in the diet tier; at 1 the w8 packed kernel took 305 and only one fitted)
   static constexpr int KREG = 2;         // line search keeps r, q in registers when d <= KREG * NT
   static constexpr bool LITE_OK = (NW == 2 && !WIDE);  // 256-register budget at full residency (two waves per SIMD)
+  // carries the "diet" LDS layout of the packed operator (H as a packed triangle, CSC + avg read in place from the
+  // store): the four-wave wide shape, which is what cones of the TSP-50 class (80 - 160 KB of LDS) are launched with
+  static constexpr bool DIET_OK = (NW == 4 && WIDE);
   struct Scratch {
     double f64[2][8];
     uint32_t u32[2][8];
@@ -223,6 +226,13 @@ struct BlockCtx {
   __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                             double reg_rel, double* dv) const {
     if (wave == 0) gj_solve_small<PMAX>(lane, H, ldh, g, act, p, reg_rel, dv);
+  }
+  // H as the packed lower triangle (diet layout).  (Tried, round 4: the two workgroups that share a compute unit in
+  // that tier solving on DIFFERENT SIMDs -- wave 0 or wave 2 by the parity of the hardware wave slot: TSP-50, B = 512
+  // 0.354 ms against 0.336 ms with both on their wave 0.  Dropped.)
+  __device__ __forceinline__ void solve_spd_tri(const double* H, const double* g, const uint8_t* act, int p, double reg_rel,
+                                                double* dv) const {
+    if (wave == 0) gj_solve_small<PMAX, true>(lane, H, 0, g, act, p, reg_rel, dv);
   }
 
   // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns

@@ -251,12 +251,13 @@ __device__ __forceinline__ void gj_partial(int lane, const double* H, int ldh, c
 // The round-1 form of the same elimination: one column at a time (v_readlane pair, hazard nop, v_fma), explicit
 // diagonal.  ~20 % slower than gj_solve_regs but it needs fewer registers, which is what counts in the 4-wave
 // kernels (128-VGPR budget: with the batched form they spill ~70 registers).
-template <int PM>
+// TRI: H is the packed lower triangle (cone_common.h tri_idx; ldh unused)
+template <int PM, bool TRI = false>
 __device__ __forceinline__ void gj_solve_regs_small(int lane, const double* H, int ldh, const double* rhs,
                                               const uint8_t* act, int p, double reg_rel, double* dv) {
   const bool live = lane < p;
   const bool my_act = live && act[lane] != 0;
-  double diag0 = (live && !my_act) ? H[lane * ldh + lane] : 0.0;
+  double diag0 = (live && !my_act) ? H[TRI ? tri_idx((uint32_t)lane, (uint32_t)lane) : (uint32_t)(lane * ldh + lane)] : 0.0;
   const double maxdiag = wave_max_f64(diag0);
   const double reg = reg_rel * maxdiag;
   double h[PM];
@@ -264,7 +265,7 @@ __device__ __forceinline__ void gj_solve_regs_small(int lane, const double* H, i
   for (int j = 0; j < PM; ++j) {
     double v = 0.0;
     if (j < p) {
-      if (live && !my_act) v = H[lane * ldh + j];
+      if (live && !my_act) v = H[TRI ? tri_idx((uint32_t)lane, (uint32_t)j) : (uint32_t)(lane * ldh + j)];
       if (j == lane) v = my_act ? 1.0 : v + reg;
     }
     h[j] = v;
@@ -294,20 +295,20 @@ __device__ __forceinline__ void gj_solve_regs_small(int lane, const double* H, i
   if (live) dv[lane] = dead ? 0.0 : b / diag;
 }
 
-template <int PLIM>
+template <int PLIM, bool TRI = false>
 __device__ __forceinline__ void gj_solve_small(int lane, const double* H, int ldh, const double* g, const uint8_t* act,
                                                int p, double reg_rel, double* dv) {
-  if (p <= 8) gj_solve_regs_small<8>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 16) gj_solve_regs_small<16>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 20) gj_solve_regs_small<20>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 24) gj_solve_regs_small<24>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 28) gj_solve_regs_small<28>(lane, H, ldh, g, act, p, reg_rel, dv);
-  else if (p <= 32) gj_solve_regs_small<32>(lane, H, ldh, g, act, p, reg_rel, dv);
+  if (p <= 8) gj_solve_regs_small<8, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 16) gj_solve_regs_small<16, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 20) gj_solve_regs_small<20, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 24) gj_solve_regs_small<24, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 28) gj_solve_regs_small<28, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 32) gj_solve_regs_small<32, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
   else if constexpr (PLIM > 32) {
-    if (p <= 40) gj_solve_regs_small<40>(lane, H, ldh, g, act, p, reg_rel, dv);
-    else if (p <= 48) gj_solve_regs_small<48>(lane, H, ldh, g, act, p, reg_rel, dv);
-    else if (p <= 56) gj_solve_regs_small<56>(lane, H, ldh, g, act, p, reg_rel, dv);
-    else gj_solve_regs_small<64>(lane, H, ldh, g, act, p, reg_rel, dv);
+    if (p <= 40) gj_solve_regs_small<40, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 48) gj_solve_regs_small<48, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else if (p <= 56) gj_solve_regs_small<56, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+    else gj_solve_regs_small<64, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
   }
 }
 

@@ -185,6 +185,7 @@ class ConeStore:
             _raise_for_status(status, "ConeStore fill")
             slot += B
         self.warm_start = False
+        self.diet_min_batch = 256  # batches up to one workgroup per compute unit keep the ordinary (faster) layout
         self.fits4 = self.max_rows <= 32  # 4-wave workgroups hold reduced systems up to 32 rows
         self.waves = 0  # 0 = choose per call
         self.large_waves = 0  # large-cone path: waves per workgroup (1, 2, 4; 0 = the library's choice)
@@ -198,11 +199,20 @@ class ConeStore:
         self.lds_bytes_big = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, 2 if self.all_pm1 else 0))
         # cones beyond the LDS-resident solver (more than 64 reduced rows or too many non-zeros) run on the
         # large-cone path, which reads the store in place and keeps the Newton systems as bands
+        # "diet" layout (include/cave_hip.h, cave_hip_packed_lds_bytes mode 3) for +-1 cones of the TSP-50 class: when the
+        # ordinary arena allows one workgroup per compute unit only (> 80 KB) and the diet one allows two, batches
+        # that fill the GPU more than once are launched with the diet figure (the kernel then takes the diet layout for
+        # the instances that need it); the indices of such a store carry the signs (flags bit 1)
+        self.lds_bytes_diet = 0
+        if self.all_pm1 and 32 < self.max_rows <= 64 and self.lds_bytes > 80 * 1024:
+            diet = int(lib.cave_hip_packed_lds_bytes(d, self.max_rows, self.max_nnz, 3))
+            if 0 < diet <= 80 * 1024:
+                self.lds_bytes_diet = diet
         self.large = self.lds_bytes <= 0 or self.max_rows > 64
         self.band_entries, self.max_bw = self._max_band_entries() if self.large else (0, 0)
         # LDS for the large path's hot arrays: ring window + staging buffers + three row vectors
         self.large_lds = int(lib.cave_hip_packed_large_lds_bytes(int(self.max_rows), int(self.max_bw))) if self.large else 0
-        if self.large:
+        if self.large or self.lds_bytes_diet:
             self._fold_signs()
         self._build_lite()
         return self
@@ -357,9 +367,12 @@ class ConeStore:
                 if zero_failed:
                     out["zero_failed"] = True
             else:
+                lds = self.lds_bytes if B <= 2048 else self.lds_bytes_big
+                if self.lds_bytes_diet and B > self.diet_min_batch and mode != _lib.MODE_INNER_IPM and self.waves in (0, 8):
+                    lds = self.lds_bytes_diet  # two workgroups per compute unit
                 rc = lib.cave_hip_cone_packed(
                     C.byref(self._c), _lib.ptr(ids), _lib.ptr(pred), B, int(mode), float(sign), float(inner_ratio),
-                    int(max_iter), self.lds_bytes if B <= 2048 else self.lds_bytes_big, self._waves_for(B),
+                    int(max_iter), lds, self._waves_for(B),
                     _lib.ptr(out.get("proj")), _lib.ptr(out.get("rnorm")), _lib.ptr(out.get("target")),
                     _lib.ptr(out.get("loss")), _lib.ptr(out.get("grad")), _lib.ptr(status), _lib.ptr(iters),
                     _lib.current_stream())

@@ -185,7 +185,11 @@ int32_t cave_hip_cone_packed(const cave_cone_store* store, const int64_t* ids, c
  * flags bit0 set, so no value arrays are staged (smaller arena -> more workgroups per CU).  all_pm1 == 1 also
  * reserves room for the index structures of the one-wave solver for small cones (d <= 256, <= 32 rows), which
  * launches of up to 2048 instances use; all_pm1 == 2: +-1 cones without that room (large batches: more
- * workgroups per CU matter more there). */
+ * workgroups per CU matter more there); all_pm1 == 3 (v9): the "diet" layout of +-1 cones with more than 32 reduced
+ * rows (TSP-50: 107 KB -> 76 KB, two workgroups per compute unit instead of one): H as a packed lower triangle, the
+ * CSC entries and the average normal read in place from the store.  It is taken, per instance, by
+ * cave_hip_cone_packed(waves = 8) when the instance's ordinary arena exceeds the lds_bytes of the launch and the
+ * store carries the signs in its indices (flags bit 1). */
 int32_t cave_hip_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1);
 
 /* ------------------------------------------------------------------ large-cone path

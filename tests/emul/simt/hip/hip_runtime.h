@@ -28,6 +28,7 @@
 #if defined(__SANITIZE_ADDRESS__)
 extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
 extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
 #endif
 
 #define __device__
@@ -238,6 +239,11 @@ inline void run_block(int nt, unsigned block_idx, unsigned grid_dim, std::functi
     }
     s.done[t] = false;
     s.par[t] = 0;
+#if defined(__SANITIZE_ADDRESS__)
+    // a lane that finished never returned from its frames (it switched away for good): their redzones are still
+    // poisoned, and the next workgroup's frames on this stack would trip over them
+    __asan_unpoison_memory_region(s.stack[t], Sim::STACK);
+#endif
 #if defined(SIMT_ASM_SWITCH)
     {  // a fresh stack that "returns" into fiber_main: [6 callee-saved registers][entry][alignment slot]
       void** top = (void**)(((uintptr_t)s.stack[t] + Sim::STACK) & ~(uintptr_t)15);

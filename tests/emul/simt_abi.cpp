@@ -108,7 +108,8 @@ void cave_simt_stats(unsigned long* out) {  // context switches, rendezvous sinc
 }
 
 int32_t cave_simt_packed_lds_bytes(int64_t d, int32_t max_rows, int32_t max_nnz, int32_t all_pm1) {
-  int32_t s = packed_lds_bytes(d, max_rows, max_nnz, all_pm1 != 0, all_pm1 != 2);
+  int32_t s = all_pm1 == 3 ? packed_lds_bytes(d, max_rows, max_nnz, true, false, true)   // the diet layout
+                           : packed_lds_bytes(d, max_rows, max_nnz, all_pm1 != 0, all_pm1 != 2);
   return s < 0 ? CAVE_E_INVALID : s;
 }
 int32_t cave_simt_packed_large_lds_bytes(int32_t max_rows, int32_t max_bw) {

@@ -262,13 +262,16 @@ class Simt:
         return out
 
     def cone_packed(self, store, arrs, max_rows, max_nnz, ids, pred, mode, sign=-1.0, inner_ratio=0.2, max_iter=0,
-                    waves=1, seed=0):
+                    waves=1, seed=0, diet=False):
+        """diet: launch with the LDS figure of the diet layout (cave_hip_packed_lds_bytes mode 3): instances whose
+        ordinary arena exceeds it take that layout (waves = 8 only; the store must carry the signs in its indices)."""
         d = store.d
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         B = len(ids)
         pred = None if pred is None else np.ascontiguousarray(pred, dtype=np.float32)
         all_pm1 = int(bool((arrs["flags"] & 1).all()))
-        lds = self.lib.cave_simt_packed_lds_bytes(C.c_int64(d), C.c_int32(max_rows), C.c_int32(max_nnz), C.c_int32(all_pm1))
+        lds = self.lib.cave_simt_packed_lds_bytes(C.c_int64(d), C.c_int32(max_rows), C.c_int32(max_nnz),
+                                                  C.c_int32(3 if diet else all_pm1))
         assert lds > 0
         out = self._outs(B, d)
         rc = self.lib.cave_simt_cone_packed(
