@@ -3,7 +3,7 @@
 # A pass whose counter set the profiler rejects is reported and skipped; a pass that is KILLED (timeout) ends the script.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/${PROF_DIR:-prof_r03}
+OUT=$R/gpurun_out/${PROF_DIR:-prof_r04}
 mkdir -p $OUT
 CMD="python3 $R/bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-extras ${BENCH_ARGS:-}"
 pass() {  # name, rocprofv3 options...

@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 passes for the large-cone kernels (configs 3 and 4, distinct cones); kernel trace and PMC in separate runs.
-#   WHICH="tsp100 sp30" PROF_TAG=r03 [CAVE_SO=variant.so] bash tools/diag/pmc_run_large.sh
+#   WHICH="tsp50 tsp100 sp30" PROF_TAG=r04 [CAVE_SO=variant.so] bash tools/diag/pmc_run_large.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for W in ${WHICH:-tsp100 sp30}; do
-  OUT=$R/gpurun_out/prof_${PROF_TAG:-r03}_$W
+for W in ${WHICH:-tsp50 tsp100 sp30}; do
+  OUT=$R/gpurun_out/prof_${PROF_TAG:-r04}_$W
   mkdir -p $OUT
   CMD="python3 $R/tools/diag/large_profile.py $W"
   pass() {

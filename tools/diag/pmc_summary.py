@@ -14,11 +14,13 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
-kerns = (sys.argv[3] if len(sys.argv) > 3 else "cone_dense_kernel").split(",")
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+kerns = (sys.argv[3] if len(sys.argv) > 3 else "cone_step_kernel").split(",")
 out = {"kernels": {}, "workload": sys.argv[4] if len(sys.argv) > 4 else "tsp20_b1024_inner",
-       "split": any("cone_pack_kernel" in k for k in kerns)}
+       "split": any("cone_pack_kernel" in k for k in kerns), "fused": any("cone_step_kernel" in k for k in kerns),
+       "fetch_size_note": "FETCH_SIZE x 2: the counter reports half of the bytes of the touched 128-byte lines for streams AND "
+                          "gathers (profiles/r04_fetch_size_gather_check.txt)"}
 tot_r = tot_w = 0.0
 for kern in kerns:
     o = {}
