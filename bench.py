@@ -367,16 +367,26 @@ def main(argv=None):
     # ---- dominant kernel duration: HIP events on the launch stream around single launches, rotating batches
     # (fused form: the one cone_step_kernel launch of a step -- solve of batch i + pack of batch i+1; back-to-back form:
     #  the two kernels of the general dense operator)
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5 * R)]
+    # groups of KG launches between two events, the stream kept busy by a launch ahead of the first event: the figure is
+    # the kernel's duration + the 2-3 us between two launches of a busy stream, not the ~6 us an idle stream needs to
+    # start one (rocprofv3's per-kernel average of the same command: profiles/r04_kernel_stats.csv, fused launches only
+    # in profiles/r04_kernel_stats_by_grid.txt)
+    KG = 4
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2 * R)]
     state["prep"] = None
     step(0)
     torch.cuda.synchronize()
-    for i, (a, b) in enumerate(kev):
+    n_k = 1
+    for a, b in kev:
+        step(n_k)
+        n_k += 1
         a.record()
-        step(i + 1)
+        for _ in range(KG):
+            step(n_k)
+            n_k += 1
         b.record()
     torch.cuda.synchronize()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in kev])) / KG
     from cave_amd import qpsolver
 
     split = qpsolver._split_ok.get((m_max, d)) is True

@@ -6,8 +6,9 @@
 The step may consist of several kernels (the split form of the dense operator launches a pack kernel and a
 solve kernel): every listed kernel is summarised on its own and the per-STEP HBM traffic is their sum.
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in
-separate passes, are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming
-read (the scan uses 16-byte loads), so the read side is doubled."""
+separate passes, are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of the touched 128-byte lines
+(streams and gathers alike: profiles/r04_fetch_size_gather_check.txt), so the read side is doubled.
+PMC_GRID=<threads>: only launches of that grid size (the fused step: 2048 workgroups x 128 threads = 262144)."""
 import csv
 import glob
 import json
@@ -30,7 +31,7 @@ for kern in kerns:
             continue
         acc = {}
         for r in csv.DictReader(open(fs[0])):
-            if kern in r["Kernel_Name"]:
+            if kern in r["Kernel_Name"] and (not os.environ.get("PMC_GRID") or r.get("Grid_Size") == os.environ["PMC_GRID"]):
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             o[k] = sum(v) / len(v)
