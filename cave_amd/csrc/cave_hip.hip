@@ -302,8 +302,9 @@ static int32_t step_limits(int64_t m_max, int64_t d, int32_t& cap, int32_t& lds)
   const uint32_t solve_lds = step_solve_lds_bytes(d);
   uint32_t need = pack_lds > solve_lds ? (uint32_t)pack_lds : solve_lds;
   need = (need + 255u) & ~255u;
-  // four solve blocks + two pack blocks per compute unit: the form only pays when six workgroups fit
-  if ((uint64_t)need * 6u > kMaxLds) return CAVE_E_INVALID;
+  // four solve blocks + two pack blocks per compute unit: the fused form only pays when six workgroups fit
+  // (a launch without a pack half -- m_max = 0: the lite slots of a device-resident store -- needs four)
+  if ((uint64_t)need * (m_max > 0 ? 6u : 4u) > kMaxLds) return CAVE_E_INVALID;
   lds = (int32_t)need;
   return CAVE_OK;
 }

@@ -228,6 +228,9 @@ __global__ __launch_bounds__(CP::NT, 2) void cone_step_kernel(StepParams P) {
 #endif
     return;
   }
+  // the pack half is the tail of the launch (its second round of workgroups starts when the first ends): its waves
+  // issue ahead of the solve wave they share a SIMD with (132.7 us per step against 134.3 without; the reverse: 133.8)
+  __builtin_amdgcn_s_setprio(1);
   CP c;
   c.init(smem);
   const int64_t q = b - P.S.B;

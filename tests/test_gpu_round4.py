@@ -161,6 +161,18 @@ def test_packed_store_serves_small_cones_from_lite_slots(golden):
         assert float((a[k] - b[k]).abs().max()) <= 1e-6 * max(1.0, float(b[k].abs().max())), k
     bad = store.cone_op(torch.tensor([0, 300, -1], device="cuda"), p[:3], MODE_PROJECT, 1.0, 0.0, check=False)
     assert bad["status"].tolist() == [0, 3, 3]   # slots out of range: BAD_INPUT, as the general kernel reports them
+    # TSP-23 (d = 253): the solve-only launch needs 4 workgroups' worth of LDS per CU, not the 6 a launch with a pack
+    # half is held to -- its store is still served from lite slots
+    c23, y23, _ = synth.tsp_batch(23, 64, seed=9)
+    s23 = ConeStore.from_dense(torch.tensor(c23))
+    assert s23.lite_slots is not None
+    i23 = torch.arange(64, device="cuda")
+    a = s23.cone_op(i23, torch.tensor(y23, device="cuda"), MODE_INNER, -1.0, 0.2, outputs=ALL)
+    s23.waves = 2
+    b = s23.cone_op(i23, torch.tensor(y23, device="cuda"), MODE_INNER, -1.0, 0.2, outputs=ALL)
+    assert bool((a["status"] == 0).all())
+    for k in ALL:
+        assert float((a[k] - b[k]).abs().max()) <= 1e-6 * max(1.0, float(b[k].abs().max())), k
     big = ctrs[:8].copy()
     big[3, :40, :30] = rng.standard_normal((40, 30)).astype(np.float32)
     gen = ConeStore.from_dense(torch.tensor(big))

@@ -53,7 +53,7 @@ def solve_report(a, it, t0, title):
 
 for _ in range(3): prepA = prepare_dense(cA)
 a = stamps()[4096:4096 + B]
-pack_report(a, a[:, 15].min(), "pack-only launch (2 workgroups per CU by registers)")
+pack_report(a, a[:, 15].min(), "pack-only launch (four two-wave workgroups per CU)")
 for _ in range(3): o = cone_op_prepared(prepA, pA, 2, -1.0, 0.2, check=False, outputs=("loss", "grad"))
 a = stamps()[:B]
 it = o["iters"].cpu().numpy().astype(np.float64)
