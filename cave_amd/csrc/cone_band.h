@@ -48,8 +48,10 @@ CAVE_HD int band_chunk_rows(int ld) {
 // (A real call, not inlined: inside the fully inlined Newton iteration its loops inherit a register file
 // already spilling; as a function they get their own allocation.)
 template <class C, bool HOT>
-CAVE_NOINLINE void solve_spd_band(C& c, const double* Hb_, int bw, const double* rhs, const uint8_t* act_, int p,
+CAVE_NOINLINE void solve_spd_band(C& c_, const double* Hb_, int bw, const double* rhs, const uint8_t* act_, int p,
                             double reg_rel, double* win_, double* fac_, double* z_, double* x_, double* stg_, int CH) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
   constexpr int NT = C::NT;
   constexpr int RMAX = (NT >= 64) ? 16 : 4096;
   constexpr int HS = HOT ? 3 : 0;   // space of the hot arrays

@@ -98,6 +98,17 @@ template <class T> struct SpacePtr<T, 3> { using type = __attribute__((address_s
 template <int SPACE, class T>
 CAVE_HD typename SpacePtr<T, SPACE>::type space_cast(T* q) { return (typename SpacePtr<T, SPACE>::type)q; }
 
+// Inside a REAL call the context, the view and the work record arrive by reference: their fields would be read through
+// FLAT loads from the caller's private memory at every use.  A local copy lives in registers (or typed scratch); the
+// context's mutable state (barrier parity, stamp counters) is handed back when the copy goes out of scope.
+template <class C>
+struct CtxLocal {
+  C& ref;
+  C c;
+  CAVE_HD explicit CtxLocal(C& x) : ref(x), c(x) {}
+  CAVE_HD ~CtxLocal() { ref = c; }
+};
+
 // per-instance status codes (also in include/cave_hip.h)
 enum : int32_t {
   ST_OK = 0,

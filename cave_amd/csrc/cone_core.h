@@ -364,17 +364,19 @@ CAVE_HD void compute_avg(C& c, const ConeBuild& cb, float* avg) {
 
 // entry e of the reduced CSR / CSC: index and value (value = sign bit of the index when v.pm1)
 // (PM1 is a compile-time copy of v.pm1 so the hot loops carry no mode test)
-template <bool PM1>
+// SP = 1: the caller knows the cone to be in GLOBAL memory (large-cone path: the packed store or the workspace; the far
+// CSC of the diet layout) -> global_* loads; 0: wherever the view points (generic pointer: flat_* inside real calls)
+template <bool PM1, int SP = 0>
 CAVE_HD void csr_entry(const SolveView& v, uint32_t e, uint32_t& col, double& val) {
-  const uint32_t x = v.mcol[e];
+  const uint32_t x = space_cast<SP>(v.mcol)[e];
   if (PM1) { col = x & 0x7fffu; val = (x & 0x8000u) ? -1.0 : 1.0; }
-  else { col = x; val = (double)v.mval[e]; }
+  else { col = x; val = (double)space_cast<SP>(v.mval)[e]; }
 }
-template <bool PM1>
+template <bool PM1, int SP = 0>
 CAVE_HD void csc_entry(const SolveView& v, uint32_t e, uint32_t& var, double& val) {
-  const uint32_t x = v.cvar[e];
+  const uint32_t x = space_cast<SP>(v.cvar)[e];
   if (PM1) { var = x & 0x7fffu; val = (x & 0x8000u) ? -1.0 : 1.0; }
-  else { var = x; val = (double)v.cvalc[e]; }
+  else { var = x; val = (double)space_cast<SP>(v.cvalc)[e]; }
 }
 
 CAVE_HD double clip_unit(double r, uint8_t u) {
@@ -713,82 +715,92 @@ __device__ __forceinline__ void lite_hessian(C& c, const LiteCone& L, const Solv
 template <class C>
 __device__ __forceinline__ bool lite_model_step(C& c, const SolveView& v, SolveWork& w, const double* theta, double* tc,
                                                 double reg_rel) {
-  const int p = v.p, nF = w.ls_nF, nI = w.ls_nI, ldS = nI | 1, lane = c.lane_id();
+  const int p = v.p, nF = w.ls_nF, nI = w.ls_nI, lane = c.lane_id();
   double* XS = w.ls_scr;          // [p * nI]  rows < nF: X_I, rows >= nF: S
   double* xg = w.step;            // [p]       rows < nF: x_g, rows >= nF: reduced right-hand side (idle otherwise)
-  double* S = XS + p * nI;        // [nI * ldS]
-  double* sg = S + nI * ldS;      // reduced model gradient at the working point
-  double* st = sg + nI;           // working point
-  double* ss = st + nI;           // step of one round
-  double* sr = ss + nI;           // right-hand side / S * step
-  uint8_t* sact = reinterpret_cast<uint8_t*>(sr + nI);
+  double* st = XS + p * nI;       // [nI]      the bound rows' multipliers the loop ends with
   double* rhs = w.g2;
   if (lane < p) rhs[lane] = -w.g[lane];
   c.sync();
   gj_partial<32, true>(lane, w.H, w.ldh, rhs, p, nF, reg_rel, XS, xg);
   c.sync();
-  for (int idx = lane; idx < nI * nI; idx += 64) {
-    const int i = idx / nI, j = idx - i * nI;
-    S[i * ldS + j] = XS[(nF + i) * nI + j];
-  }
-  c.sync();
   bool moved = false;
+  constexpr int NM = 8;  // (the lite form takes at most 8 bound rows)
+  const bool mine = lane < nI;
+  const int row = nF + lane;
   for (int attempt = 0; attempt < 2 && !moved; ++attempt) {
     double gmin = 0.0;
     if (attempt == 1) {
       double gl = 0.0;
-      if (lane < nI && theta[nF + lane] <= 0.0) gl = fmin(gl, w.g[nF + lane]);
+      if (mine && theta[row] <= 0.0) gl = fmin(gl, w.g[row]);
       gmin = -c.reduce_max(-gl);
       if (!(gmin < 0.0)) break;
     }
-    if (lane < nI) {
-      const int row = nF + lane;
-      const bool at_bound = theta[row] <= 0.0;
+    // The active-set loop on the Schur complement, in registers (wave_prims.h tableau_exchange): lane i < nI holds row i
+    // of [S + reg I | c], c = (reduced gradient at theta) - S theta_I, i.e. the model in ABSOLUTE coordinates -- its
+    // minimiser over a free set, with the other rows at 0, does not depend on the working point.  Free rows are
+    // exchanged in once; every round reads the minimiser off the constant column, takes the ratio test from the working
+    // point towards it, and exchanges the blocking row(s) back out.  Same iterates as the round-by-round solves this
+    // replaces (which cost the slowest instances of a TSP-20 batch ~10 k cycles per Newton iteration).
+    const double th_i = mine ? theta[row] : 0.0;
+    bool act = false, frozen = false;
+    if (mine) {
+      const bool at_bound = th_i <= 0.0;
       const bool release = attempt == 0 ? (w.g[row] < 0.0) : (w.g[row] <= gmin);
-      sact[lane] = (uint8_t)((at_bound && !release) ? 1 : 0);
-      st[lane] = theta[row];
-      sg[lane] = -xg[row];
+      act = at_bound && !release;
     }
-    c.sync();
+    double T[NM + 1];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) T[j] = (mine && j < nI) ? XS[row * nI + j] : ((j == lane) ? 1.0 : 0.0);
+    const double dmax = max8_f64((mine && !act) ? XS[row * nI + lane] : 0.0);
+    const double reg2 = reg_rel * dmax;
+    double c0 = mine ? -xg[row] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      if (j == lane && mine) T[j] += reg2;
+      c0 -= T[j] * readlane_f64(th_i, j);  // (theta of rows >= nI reads as 0)
+    }
+    T[NM] = c0;
+    double st_i = th_i;
+    uint32_t fmask = (uint32_t)__ballot(mine && !act) & 0xffu;
+    static_for<0, NM>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      if ((fmask >> J) & 1u)
+        if (!tableau_exchange<NM, J>(T, lane)) frozen = frozen || (lane == J);
+    });
     for (int inner = 0; inner <= nI; ++inner) {
-      if (lane < nI) sr[lane] = sact[lane] ? -st[lane] : -sg[lane];
-      c.sync();
-      c.solve_spd(S, ldS, sr, sact, nI, reg_rel, ss);
-      c.sync();
+      const bool fr = mine && !act && !frozen;
+      const double t = fr ? T[NM] : (act ? 0.0 : st_i);
       double amin = 2.0;
-      if (lane < nI && !sact[lane]) {
-        const double t = st[lane] + ss[lane];
-        if (t < 0.0) amin = fmin(amin, st[lane] / (st[lane] - t));
-      }
-      amin = -c.reduce_max(-amin);
+      if (fr && t < 0.0) amin = st_i / (st_i - t);
+      amin = min8_f64(amin);
       const bool blocked = amin < 1.0;
       const double a = blocked ? fmax(amin, 0.0) : 1.0;
-      double hs = 0.0;
-      if (blocked && lane < nI)
-        for (int j = 0; j < nI; ++j) hs += S[lane * ldS + j] * ss[j];
-      if (lane < nI) {
-        const double t = st[lane] + ss[lane];
-        double tn = st[lane] + a * ss[lane];
-        uint8_t act = sact[lane];
-        if (!act && blocked && t < 0.0 && st[lane] <= a * (st[lane] - t) * (1.0 + 1e-12)) {
-          tn = 0.0;
-          act = 1;
-        }
-        if (act) tn = 0.0;
-        c.sync();  // (every lane has read ss / st / sact of this round)
-        sact[lane] = act;
-        st[lane] = tn;
-        if (blocked) sg[lane] += a * hs;
-      } else c.sync();
-      c.sync();
+      const bool fixnow = fr && blocked && t < 0.0 && st_i <= a * (st_i - t) * (1.0 + 1e-12);
+      double tn = blocked ? st_i + a * (t - st_i) : t;
+      if (fixnow || act) tn = 0.0;
+      st_i = tn;
+      act = act || fixnow;
       if (!blocked) break;
+      fmask = (uint32_t)__ballot(fixnow) & 0xffu;
+      static_for<0, NM>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if ((fmask >> J) & 1u) tableau_exchange<NM, J>(T, lane);
+      });
     }
+    if (mine) st[lane] = st_i;
+    double du[NM];  // displacement of the bound rows, broadcast (wave-uniform code: not inside the lane tests below)
+#pragma unroll
+    for (int j = 0; j < NM; ++j) du[j] = readlane_f64(st_i - th_i, j);  // (lanes >= nI: 0)
+    c.sync();
     double mv = 0.0;
     if (lane < p) {
       double t;
       if (lane < nF) {
         double x = xg[lane];
-        for (int j = 0; j < nI; ++j) x -= XS[lane * nI + j] * (st[j] - theta[nF + j]);
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+          if (j < nI) x -= XS[lane * nI + j] * du[j];
         t = theta[lane] + x;
       } else t = st[lane - nF];
       tc[lane] = t;
@@ -872,6 +884,7 @@ template <class C, bool PM1, class W>
 CAVE_HD void band_hessian(C& c, const SolveView& v, SolveWork& w, bool in_lds, W&& weight) {
   constexpr int NT = C::NT;
   const int p = v.p, d = v.d, ldh = w.ldh;
+  const auto cptr = space_cast<1>(v.cptr);  // large-cone path: the view is global memory
   auto accumulate = [&](auto Hacc, auto add) {
     for (int idx = c.tid(); idx < p * ldh; idx += NT) Hacc[idx] = 0.0;
     c.sync();
@@ -887,16 +900,16 @@ CAVE_HD void band_hessian(C& c, const SolveView& v, SolveWork& w, bool in_lds, W
         const int k = base + u * NT;
         const bool in = k < d;
         const int kc = in ? k : d - 1;
-        lo[u] = v.cptr[kc];
-        hi[u] = in ? v.cptr[kc + 1] : lo[u];
+        lo[u] = cptr[kc];
+        hi[u] = in ? cptr[kc + 1] : lo[u];
         wk[u] = in ? weight(kc) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < G; ++u) {
-        const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;  // clamp: loads are unconditional
+        const uint32_t last = cptr[d] > 0u ? cptr[d] - 1u : 0u;  // clamp: loads are unconditional
         const uint32_t e0 = lo[u] < last ? lo[u] : last, e1 = lo[u] + 1u < last ? lo[u] + 1u : last;
-        csc_entry<PM1>(v, e0, a0[u], x0[u]);
-        csc_entry<PM1>(v, e1, a1[u], x1[u]);
+        csc_entry<PM1, 1>(v, e0, a0[u], x0[u]);
+        csc_entry<PM1, 1>(v, e1, a1[u], x1[u]);
       }
 #pragma unroll
       for (int u = 0; u < G; ++u) {
@@ -909,11 +922,11 @@ CAVE_HD void band_hessian(C& c, const SolveView& v, SolveWork& w, bool in_lds, W
         for (uint32_t e1 = lo[u] + 2u; e1 < hi[u]; ++e1) {  // columns with more than two entries (cut rows)
           uint32_t a, b;
           double v1, v2;
-          csc_entry<PM1>(v, e1, a, v1);
+          csc_entry<PM1, 1>(v, e1, a, v1);
           const double va = wk[u] * v1;
           add(Hacc + a * ldh, va * v1);
           for (uint32_t e2 = lo[u]; e2 < e1; ++e2) {
-            csc_entry<PM1>(v, e2, b, v2);
+            csc_entry<PM1, 1>(v, e2, b, v2);
             add(Hacc + (b * ldh + (a - b)), va * v2);
           }
         }
@@ -957,13 +970,14 @@ template <class C, bool PM1>
 CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double* rc, double* g) {
   constexpr int U = 4, WL = C::WL, NW = C::NWAVES;
   const int lane = c.lane_id();
-  const uint32_t last = v.mptr[v.p] > 0u ? v.mptr[v.p] - 1u : 0u;
+  const auto mptr = space_cast<1>(v.mptr);
+  const uint32_t last = mptr[v.p] > 0u ? mptr[v.p] - 1u : 0u;
   for (int l0 = c.wave_id(); l0 < v.nlong; l0 += 2 * NW) {
     const int l1 = l0 + NW;
     const bool two = l1 < v.nlong;
     const int i0 = (int)v.longrow[l0], i1 = two ? (int)v.longrow[l1] : i0;
-    const uint32_t lo0 = v.mptr[i0], n0 = v.mptr[i0 + 1] - lo0;
-    const uint32_t lo1 = v.mptr[i1], n1 = two ? v.mptr[i1 + 1] - lo1 : 0u;
+    const uint32_t lo0 = mptr[i0], n0 = mptr[i0 + 1] - lo0;
+    const uint32_t lo1 = mptr[i1], n1 = two ? mptr[i1 + 1] - lo1 : 0u;
     double part0 = 0.0, part1 = 0.0;
     for (uint32_t off = 0; off < n0 || off < n1; off += (uint32_t)(U * WL)) {
       uint32_t col[2][U];
@@ -972,8 +986,8 @@ CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double*
       for (int u = 0; u < U; ++u) {
         const uint32_t t = off + (uint32_t)(u * WL + lane);
         const uint32_t e0 = lo0 + t < last ? lo0 + t : last, e1 = lo1 + t < last ? lo1 + t : last;  // clamped, unconditional
-        csr_entry<PM1>(v, e0, col[0][u], val[0][u]);
-        csr_entry<PM1>(v, e1, col[1][u], val[1][u]);
+        csr_entry<PM1, 1>(v, e0, col[0][u], val[0][u]);
+        csr_entry<PM1, 1>(v, e1, col[1][u], val[1][u]);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) { x[0][u] = rc[col[0][u]]; x[1][u] = rc[col[1][u]]; }
@@ -1000,11 +1014,14 @@ CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double*
 // reduction (entries s, s + 4, .. in partial sum s; (p0 + p1) + (p2 + p3)), so the bits are the same.  A real call:
 // its ~100 live registers would otherwise spill inside the Newton iteration.
 template <class C, bool PM1>
-CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const double* rc, double* g) {
+CAVE_NOINLINE void gradient_short_rows_streamed(C& c_, const SolveView& v_, const double* rc, double* g) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const SolveView v = v_;
   constexpr int R = 8, Q = 4, NT = C::NT;
   static_assert(C::TEAM == Q, "partial sums follow the quad reduction of gradient()");
   const int p = v.p, tid = c.tid();
-  const uint32_t* mptr = v.mptr;
+  const auto mptr = space_cast<1>(v.mptr);
   const uint32_t last = mptr[p] > 0u ? mptr[p] - 1u : 0u;
   for (int i0 = tid; i0 < p; i0 += R * NT) {
     uint32_t lo[R], n[R], col[R][Q];
@@ -1033,7 +1050,7 @@ CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const 
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const uint32_t e = lo[u] + (uint32_t)q < last ? lo[u] + (uint32_t)q : last;  // clamped, unconditional
-        csr_entry<PM1>(v, e, col[u][q], val[u][q]);
+        csr_entry<PM1, 1>(v, e, col[u][q], val[u][q]);
       }
 #pragma unroll
     for (int u = 0; u < R; ++u)
@@ -1054,7 +1071,7 @@ CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const 
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
           const uint32_t e = lo[u] + off + (uint32_t)q < last ? lo[u] + off + (uint32_t)q : last;
-          csr_entry<PM1>(v, e, c2[q], v2[q]);
+          csr_entry<PM1, 1>(v, e, c2[q], v2[q]);
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) x2[q] = rc[c2[q]];
@@ -1068,11 +1085,12 @@ CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const 
 }
 
 // out[k] = base[k] + sgn * (M^T th)[k], G columns per thread at a time (extents, then entries, then operands)
-template <class C, bool PM1>
+template <class C, bool PM1, int CP = 0>
 CAVE_HD void gather_mt_streamed(C& c, const SolveView& v, const float* base, const double* th, double sgn, double* out) {
   constexpr int G = 4, E = 3, NT = C::NT;
   const int d = v.d;
-  const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
+  const auto cptr = space_cast<CP>(v.cptr);  // CP = 1: large-cone path; 0: diet layout (column pointers in LDS)
+  const uint32_t last = cptr[d] > 0u ? cptr[d] - 1u : 0u;
   for (int k0 = c.tid(); k0 < d; k0 += G * NT) {
     uint32_t lo[G], cnt[G], a[G][E];
     double x[G][E], t[G][E], r[G];
@@ -1081,8 +1099,8 @@ CAVE_HD void gather_mt_streamed(C& c, const SolveView& v, const float* base, con
       const int k = k0 + u * NT;
       const bool in = k < d;
       const int kc = in ? k : d - 1;
-      lo[u] = v.cptr[kc];
-      cnt[u] = in ? v.cptr[kc + 1] - lo[u] : 0u;
+      lo[u] = cptr[kc];
+      cnt[u] = in ? cptr[kc + 1] - lo[u] : 0u;
       r[u] = base ? (double)base[kc] : 0.0;
     }
 #pragma unroll
@@ -1090,7 +1108,7 @@ CAVE_HD void gather_mt_streamed(C& c, const SolveView& v, const float* base, con
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const uint32_t ee = lo[u] + (uint32_t)e < last ? lo[u] + (uint32_t)e : last;
-        csc_entry<PM1>(v, ee, a[u][e], x[u][e]);
+        csc_entry<PM1, 1>(v, ee, a[u][e], x[u][e]);
       }
 #pragma unroll
     for (int u = 0; u < G; ++u)
@@ -1110,7 +1128,7 @@ CAVE_HD void gather_mt_streamed(C& c, const SolveView& v, const float* base, con
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
           const uint32_t ee = lo[u] + e0 + j < last ? lo[u] + e0 + j : last;
-          csc_entry<PM1>(v, ee, var[j], val[j]);
+          csc_entry<PM1, 1>(v, ee, var[j], val[j]);
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) tv[j] = th[var[j]];
@@ -1137,7 +1155,7 @@ CAVE_HD void gather_any(C& c, const SolveView& v, const float* base, const doubl
 #if defined(CAVE_GPU_CODE)
   if constexpr (ctx_lite<C>::value) { lite_gather(c, c.lite, v.d, base, th, sgn, out); return; }
 #endif
-  if constexpr (STREAMED && C::WL > 1) gather_mt_streamed<C, PM1>(c, v, base, th, sgn, out);
+  if constexpr (STREAMED && C::WL > 1) gather_mt_streamed<C, PM1, 1>(c, v, base, th, sgn, out);
   else {
     if constexpr (ctx_diet<C>::value && PM1) {
       if (v.csc_far) { gather_mt_streamed<C, PM1>(c, v, base, th, sgn, out); return; }  // CSC in the store: batched loads
@@ -1740,8 +1758,8 @@ CAVE_HD SolveResult solve_cone(C& c, const SolveView& v, SolveWork& w, int max_i
 // cone build of the persistent large kernels it inherited (and added to) a register file that spilled 150-250
 // VGPRs; as a function it gets its own allocation and only the call boundary saves registers.
 template <class C>
-CAVE_NOINLINE void solve_cone_band_call(C& c, const SolveView& v, SolveWork& w, int max_iter, double tol, SolveResult* out) {
-  *out = solve_cone<C, true>(c, v, w, max_iter, tol);
+CAVE_NOINLINE void solve_cone_band_call(C& c_, const SolveView& v, SolveWork& w, int max_iter, double tol, SolveResult* out) {
+  *out = solve_cone<C, true>(c_, v, w, max_iter, tol);
 }
 
 // ------------------------------------------------- truncated interior-point projection (MODE_IPM)
@@ -1946,8 +1964,13 @@ CAVE_HD SolveResult solve_cone_ipm(C& c, const SolveView& v, SolveWork& w, int s
 }
 // large-cone path (a real call, like solve_cone_band_call)
 template <class C>
-CAVE_NOINLINE void solve_cone_ipm_band_call(C& c, const SolveView& v, SolveWork& w, int steps, SolveResult* out) {
+CAVE_NOINLINE void solve_cone_ipm_band_call(C& c_, const SolveView& v_, SolveWork& w_, int steps, SolveResult* out) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const SolveView v = v_;
+  SolveWork w = w_;
   *out = v.pm1 ? solve_cone_ipm_impl<C, true, true>(c, v, w, steps) : solve_cone_ipm_impl<C, false, true>(c, v, w, steps);
+  w_ = w;
 }
 
 // half bandwidth of M M^T in the reduced-row order: the widest span of reduced rows meeting in one

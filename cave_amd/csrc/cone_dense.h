@@ -82,10 +82,15 @@ CAVE_HD void dense_order(C& c, const SolveView& v, DenseWork& dw, uint32_t* tmp)
 // (The pieces below are REAL calls, like the band solvers: inlined into the Newton iteration they inherit -- and add
 //  to -- a register file that already spills; as functions each gets its own allocation.)
 template <class C, bool PM1, class W>
-CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const DenseWork& dw) {
+CAVE_NOINLINE void dense_hessian(C& c_, const SolveView& v_, W weight, const DenseWork& dw_) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const SolveView v = v_;
+  const DenseWork dw = dw_;
   constexpr int NT = C::NT;
   const int p = v.p, d = v.d;
   const int ne = (int)fold_entries(p);
+  const auto cptr = space_cast<1>(v.cptr);  // large-cone path: the view is global memory
   auto Aq = space_cast<3>(reinterpret_cast<long long*>(dw.A));
   auto Ad = space_cast<3>(dw.A);
   auto pos = space_cast<3>(dw.pos);
@@ -106,7 +111,7 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const Dense
   // dependent global loads per PAIR, and the instances with three to five large cuts -- the slowest of a TSP-100 batch,
   // i.e. the kernel time -- spent 410 k cycles per Hessian there against 110 k for the median instance.
   constexpr int G = 4, E = 8;
-  const uint32_t last = v.cptr[d] > 0u ? v.cptr[d] - 1u : 0u;
+  const uint32_t last = cptr[d] > 0u ? cptr[d] - 1u : 0u;
   for (int kb = c.tid(); kb < d; kb += G * NT) {
     uint32_t lo[G], cnt[G], a[G][E];
     double wk[G], x[G][E];
@@ -115,8 +120,8 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const Dense
       const int k = kb + u * NT;
       const bool in = k < d;
       const int kc = in ? k : d - 1;
-      lo[u] = v.cptr[kc];
-      cnt[u] = in ? v.cptr[kc + 1] - lo[u] : 0u;
+      lo[u] = cptr[kc];
+      cnt[u] = in ? cptr[kc + 1] - lo[u] : 0u;
       wk[u] = in ? weight(kc) : 0.0;
     }
 #pragma unroll
@@ -124,7 +129,7 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const Dense
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const uint32_t ee = lo[u] + (uint32_t)e < last ? lo[u] + (uint32_t)e : last;  // clamped: loads are unconditional
-        csc_entry<PM1>(v, ee, a[u][e], x[u][e]);
+        csc_entry<PM1, 1>(v, ee, a[u][e], x[u][e]);
       }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -142,11 +147,11 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const Dense
       for (uint32_t e1 = (uint32_t)E; e1 < cnt[u]; ++e1) {  // columns with more than E entries (edges inside several cuts)
         uint32_t a1, a2;
         double v1, v2;
-        csc_entry<PM1>(v, lo[u] + e1, a1, v1);
+        csc_entry<PM1, 1>(v, lo[u] + e1, a1, v1);
         const double va = wk[u] * v1;
         const int p1 = (int)pos[a1];
         for (uint32_t e2 = 0; e2 <= e1; ++e2) {
-          csc_entry<PM1>(v, lo[u] + e2, a2, v2);
+          csc_entry<PM1, 1>(v, lo[u] + e2, a2, v2);
           add(p1, (int)pos[a2], va * v2);
         }
       }
@@ -168,7 +173,10 @@ CAVE_NOINLINE void dense_hessian(C& c, const SolveView& v, W weight, const Dense
 // after one barrier every lane takes the same TWO COLUMNS of every trailing row, so the eight pivot-row operands are
 // read once per step and a trailing row costs four broadcast reads, one read and one write of the target pair.
 template <class C>
-CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel, int npiv = -1) {
+CAVE_NOINLINE void dense_factor(C& c_, const DenseWork& dw_, int p, double reg_rel, int npiv = -1) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const DenseWork dw = dw_;
   constexpr int NT = C::NT, NB = kDenseNB;
   const int nF = npiv >= 0 ? npiv : dw.nF;  // (npiv = p: complete factorisation, interior-point steps)
   auto A = space_cast<3>(dw.A);
@@ -334,7 +342,10 @@ CAVE_NOINLINE void dense_factor(C& c, const DenseWork& dw, int p, double reg_rel
 
 // x[q], q < nF, from the factor of the first block, the eliminated right-hand side and the given x[nF ..]
 template <class C>
-CAVE_NOINLINE void dense_backsub(C& c, const DenseWork& dw, int p, int npiv = -1) {
+CAVE_NOINLINE void dense_backsub(C& c_, const DenseWork& dw_, int p, int npiv = -1) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const DenseWork dw = dw_;
   const int nF = npiv >= 0 ? npiv : dw.nF;
   auto A = space_cast<3>(dw.A);
   auto z = space_cast<3>(dw.z);
@@ -386,8 +397,12 @@ CAVE_NOINLINE void dense_backsub(C& c, const DenseWork& dw, int p, int npiv = -1
 // variable with a negative gradient, attempt 1 -- only if that made no move -- the most negative one);
 // returns whether tc differs from theta.  dw.A must hold the Hessian (dense_hessian).
 template <class C>
-CAVE_NOINLINE bool dense_model_step(C& c, const SolveView& v, const DenseWork& dw, const double* theta, const double* g,
+CAVE_NOINLINE bool dense_model_step(C& c_, const SolveView& v_, const DenseWork& dw_, const double* theta, const double* g,
                               double* tc, double reg_rel) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const SolveView v = v_;
+  const DenseWork dw = dw_;
   constexpr int NT = C::NT;
   const int p = v.p, nF = dw.nF, nI = dw.nI, ldS = dw.ldS;
   auto A = space_cast<3>(dw.A);

@@ -77,7 +77,7 @@ struct BlockCtx {
   static_assert(sizeof(Scratch) <= SCRATCH_BYTES && NW <= 8, "scratch layout");
   int lane, wave, t;
   uint32_t par;
-  Scratch* sc;
+  typename SpacePtr<Scratch, 3>::type sc;  // LDS-typed: ds_* also inside real calls (a generic pointer member compiles to flat_*)
 #ifdef CAVE_STAMPS
   unsigned long long st[32];  // [0,16) exported per instance; [16,32) scratch slots of the fine stamps
 #endif
@@ -86,7 +86,7 @@ struct BlockCtx {
     lane = t & 63;
     wave = t >> 6;
     par = 0;
-    sc = reinterpret_cast<Scratch*>(smem);
+    sc = space_cast<3>(reinterpret_cast<Scratch*>(smem));
   }
   // hand three words from wave 0 to the whole workgroup (one barrier)
   __device__ __forceinline__ void broadcast_from_wave0(double& a, int& b, int& c) {

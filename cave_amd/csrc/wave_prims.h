@@ -248,6 +248,54 @@ __device__ __forceinline__ void gj_partial(int lane, const double* H, int ldh, c
   else if constexpr (PLIM >= 32) gj_partial_regs<32, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
 }
 
+// ---- active-set loop of a small SPD system in registers (lite_model_step, cone_core.h)
+// Tableau of  y = S x + c , one row per lane (lanes 0 .. NM-1), columns 0 .. NM-1 and the constant column NM.  A Jordan
+// EXCHANGE of pivot (J, J) swaps the roles of x_J and y_J:
+//     T'[J][J] = 1/d,   T'[J][k] = -T[J][k]/d,   T'[i][J] = T[i][J]/d,   T'[i][k] = T[i][k] - T[i][J] T[J][k]/d      (d = T[J][J]).
+// With the free variables exchanged (their y = 0) and the others at x = 0, the constant column of an exchanged row IS the
+// minimiser's x_J, and of the other rows the gradient there.  Fixing a variable at its bound = exchanging it back (the
+// step is an involution), one rank-one update of NM + 1 columns (~250 cycles) where the loop used to run a fresh
+// Gauss-Jordan of the whole system per round (~1.6 k cycles + its LDS traffic).  Lane J uses the multiplier (d + 1)/d,
+// so its row needs no separate code path; the pivot row is read G columns at a time (see gj_solve_regs).
+// Returns false (and changes nothing) when the pivot is not positive.
+template <int NM, int J, int G = 4>
+__device__ __forceinline__ bool tableau_exchange(double (&T)[NM + 1], int lane) {
+  const double d = readlane_f64(T[J], J);
+  if (!(d > 1e-300)) return false;  // wave-uniform
+  double inv = __builtin_amdgcn_rcp(d);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
+  inv = fma(fma(-d, inv, 1.0), inv, inv);
+  const double f = (T[J] + ((lane == J) ? 1.0 : 0.0)) * inv;
+  constexpr int NC = NM + 1;
+  static_for<0, (NC + G - 1) / G>([&](auto gc) {
+    constexpr int k0 = decltype(gc)::value * G;
+    double sv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (k0 + g < NC && k0 + g != J) sv[g] = readlane_f64(T[k0 + g], J);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (k0 + g < NC && k0 + g != J) T[k0 + g] -= f * sv[g];
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  T[J] = (lane == J) ? inv : f;
+  return true;
+}
+// minimum over lanes 0 .. 7 (the other lanes must hold a neutral value); every lane gets it
+__device__ __forceinline__ double min8_f64(double v) {
+  v = fmin(v, dpp_f64<0xb1, 0xf>(v, v));
+  v = fmin(v, dpp_f64<0x4e, 0xf>(v, v));
+  v = fmin(v, dpp_f64<0x114, 0xf>(v, v));  // row_shr:4: lanes 4 .. 7 now hold the minimum of both quads
+  return readlane_f64(v, 7);
+}
+__device__ __forceinline__ double max8_f64(double v) {
+  v = fmax(v, dpp_f64<0xb1, 0xf>(v, v));
+  v = fmax(v, dpp_f64<0x4e, 0xf>(v, v));
+  v = fmax(v, dpp_f64<0x114, 0xf>(v, v));
+  return readlane_f64(v, 7);
+}
+
 // The round-1 form of the same elimination: one column at a time (v_readlane pair, hazard nop, v_fma), explicit
 // diagonal.  ~20 % slower than gj_solve_regs but it needs fewer registers, which is what counts in the 4-wave
 // kernels (128-VGPR budget: with the batched form they spill ~70 registers).
