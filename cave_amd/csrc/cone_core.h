@@ -1272,6 +1272,11 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   int it = 0;
   CAVE_T0();
   for (; p > 0 && it < max_iter; ++it, cap07 *= CAVE_MU_CAP, sched01 *= CAVE_BMU_DECAY) {
+#if defined(CAVE_GPU_CODE) && defined(CAVE_LITE_TAIL_PRIO_IT)
+    // step kernel: an instance still iterating after CAVE_LITE_TAIL_PRIO_IT rounds is the tail of its launch -- its wave
+    // issues ahead of the pack waves it shares a SIMD with from here on
+    if constexpr (ctx_lite<C>::value) if (it == CAVE_LITE_TAIL_PRIO_IT) __builtin_amdgcn_s_setprio(3);
+#endif
     // gradient g = -M Pi(r) and projected-gradient norm
     CAVE_ACCF(22);
     gradient_any<C, PM1, BAND>(c, v, rc, w.g);

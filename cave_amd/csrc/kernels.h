@@ -202,6 +202,12 @@ __device__ __forceinline__ void step_release(uint32_t* masks, uint32_t claim) {
   if (claim) atomicAnd(&masks[claim >> 4], ~(claim & 15u));
 }
 
+#ifndef CAVE_STEP_PACK_PRIO
+#define CAVE_STEP_PACK_PRIO 1   // wave priorities of the two halves (A/B builds: tools/diag/build_variant.sh)
+#endif
+#ifndef CAVE_STEP_SOLVE_PRIO
+#define CAVE_STEP_SOLVE_PRIO 0
+#endif
 template <class CP>
 __global__ __launch_bounds__(CP::NT, 2) void cone_step_kernel(StepParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(CP::NT, 2) void cone_step_kernel(StepParams P) {
     uint32_t claim = 0;
     const int sel = step_elect_wave<CP::NWAVES>(smem, P.tickets, claim);
     if ((int)(threadIdx.x >> 6) != sel) return;
+    if (CAVE_STEP_SOLVE_PRIO) __builtin_amdgcn_s_setprio(CAVE_STEP_SOLVE_PRIO);
     SoloCtx<32, 4> sc;
     sc.lane = (int)(threadIdx.x & 63u);
 #ifdef CAVE_STAMPS
@@ -228,9 +235,13 @@ __global__ __launch_bounds__(CP::NT, 2) void cone_step_kernel(StepParams P) {
 #endif
     return;
   }
-  // the pack half is the tail of the launch (its second round of workgroups starts when the first ends): its waves
-  // issue ahead of the solve wave they share a SIMD with (132.7 us per step against 134.3 without; the reverse: 133.8)
-  __builtin_amdgcn_s_setprio(1);
+  // the pack half's second round of workgroups starts when the first ends: its waves issue ahead of the solve wave they
+  // share a SIMD with (k_step.hip has the measurements)
+#ifdef CAVE_STEP_PACK_PRIO_FIRST   // (A/B) only the first CAVE_STEP_PACK_PRIO_FIRST pack workgroups run at the raised priority
+  if ((int64_t)blockIdx.x - P.S.B < CAVE_STEP_PACK_PRIO_FIRST) __builtin_amdgcn_s_setprio(CAVE_STEP_PACK_PRIO);
+#else
+  if (CAVE_STEP_PACK_PRIO) __builtin_amdgcn_s_setprio(CAVE_STEP_PACK_PRIO);
+#endif
   CP c;
   c.init(smem);
   const int64_t q = b - P.S.B;
