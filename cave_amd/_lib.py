@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libcave_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
-_HEADERS = [os.path.join(_CSRC, n) for n in ("kernels.h", "cone_common.h", "cone_core.h", "cone_band.h", "cone_dense.h", "cone_instance.h", "cone_step.h",
+_HEADERS = [os.path.join(_CSRC, n) for n in ("kernels.h", "cone_common.h", "cone_core.h", "cone_band.h", "cone_dense.h", "cone_rb.h", "cone_instance.h", "cone_step.h",
                                              "wave_prims.h", "ctx_wave.h", "ctx_block.h")] + \
     [os.path.join(_ROOT, "include", "cave_hip.h")]
 # translation units: the C ABI (host code) + one file per kernel shape (cave_amd/csrc/kernels.h)

@@ -224,6 +224,25 @@ struct BandGen {
   double hdiag;           // bound on the diagonal of H (largest squared row norm): scale of the Levenberg shift
 };
 
+// Red-black reduction of the Newton systems of band cones without bound rows (cone_rb.h): an independent set of reduced
+// rows ("red": no two of them share a coordinate -- every other node of a grid) is eliminated in closed form, the band
+// LDL^T runs on the Schur complement of the others ("black").  All arrays live in the workspace block of the band,
+// which such cones never materialise.
+struct RbWork {
+  bool on;
+  int nB;          // black rows
+  uint8_t* cls;    // [p] 1 = red, 2 = black
+  uint16_t* pos;   // [p] black rows: position in the reduced system
+  uint32_t* blk;   // [nB] reduced row at position q
+  double* wt;      // [d] smoothed weight of each coordinate, this iteration
+  double* hd;      // [p] diagonal of H + shift (red rows: its reciprocal, 0 = dropped)
+  double* S;       // [nB * ldh] band of the Schur complement, S[q * ldh + t] = S(q, q + t)
+  double* gB;      // [nB] reduced right-hand side
+  uint32_t* rp;    // [nB + 1] recipe of row q of S: entries rp[q] .. rp[q + 1]
+  uint32_t* rec;   // two words per entry (cone_rb.h)
+  uint32_t* radj;  // [p * 4] red rows: their (coordinate, black neighbour) pairs
+};
+
 // Dense reduced systems of the large-cone path (cone_dense.h): everything in LDS
 struct DenseWork {
   bool on;         // this instance takes the dense path
@@ -274,6 +293,7 @@ struct SolveWork {
   double hscale, hinv;  // fixed-point scale of the band Hessian's accumulation (large-cone path) and its reciprocal
   DenseWork dn;    // dense form (p <= bw + 1, p <= 128: TSP-100)
   BandGen gen;     // band rows on demand (band_wave, no bound rows: grid shortest path)
+  RbWork rb;       // ... and their red-black reduction
   // lite solver with few bound rows (TSP-20: 20 free degree rows + <= 5 cut rows): partial elimination of the free
   // rows + active-set loop on the Schur complement of the bound rows (cone_core.h lite_model_step)
   bool ls_on;

@@ -873,6 +873,7 @@ CAVE_HD double exact_step(EVAL&& eval, double psi0, double amax) {
 
 }  // namespace cave
 #include "cone_dense.h"
+#include "cone_rb.h"
 namespace cave {
 
 // w.H = M W M^T as a symmetric band (H[j * ldh + t] = H(j + t, j)), W_kk = weight(k).  Accumulated in 64-bit FIXED
@@ -1543,7 +1544,8 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         CAVE_ACC(4);
         if constexpr (BAND) {
 #if defined(CAVE_GPU_CODE)
-          if (w.band_wave) {
+          if (w.band_wave && w.rb.on) rb_solve(c, v, w, rhs, reg_rel);  // half the rows (cone_rb.h)
+          else if (w.band_wave) {
             solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), w.H, w.bw, rhs, w.act, p, reg_rel, w.bwin, w.bfac, w.bz, w.step,
                                            &w.gen
 #ifdef CAVE_STAMPS

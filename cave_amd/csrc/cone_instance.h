@@ -182,6 +182,8 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     bool warm_on = false;
     if (warm_theta && warm_state) warm_on = c.reduce_add_u32(c.tid() == 0 ? (uint32_t)(*warm_state == 1) : 0u) != 0u;
     w.warm = warm_on ? warm_theta : nullptr;
+    bool rb_wanted = false;
+    (void)rb_wanted;
     if constexpr (LARGE) {
       const int bw = band_halfwidth(c, v);
       const uint32_t ld = (uint32_t)bw + 1u;
@@ -192,6 +194,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       // folded, and factor it once per Newton iteration (cone_dense.h).
       w.dn.on = false;
       w.gen.on = false;
+      w.rb.on = false;
       {  // fixed-point scale of the Hessian accumulation: |H_ab| <= (largest entry)^2 * (longest row)
         double vm = v.pm1 ? 1.0 : 0.0, ml = 1.0;
         if (!v.pm1) {  // (eight entries per thread in flight: the values are in global memory on this path)
@@ -320,6 +323,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
           gn.mptr = v.mptr; gn.mcol = v.mcol; gn.mval = v.pm1 ? nullptr : v.mval;
           gn.cptr = v.cptr; gn.cvar = v.cvar; gn.cvalc = v.pm1 ? nullptr : v.cvalc;
           gn.usign = v.usign; gn.r = nullptr; gn.mu = 0.0; gn.hdiag = hd;
+          rb_wanted = true;
 #ifdef CAVE_EMUL_COUNTERS
           if (c.tid() == 0) ++emul_counters()[3];
 #endif
@@ -327,9 +331,13 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       }
 #endif
       } else w.H = nullptr;
+#if defined(CAVE_GPU_CODE) && !defined(CAVE_NO_RB)  // (diagnostic builds can pin the full-size band)
+      if (rb_wanted && mode != MODE_IPM) rb_setup(c, v, w);
+#endif
     } else {
       w.dn.on = false;
       w.gen.on = false;
+      w.rb.on = false;
       if (p > C::PMAX) return ST_TOO_LARGE;
       w.hscale = 1.0;
       w.hinv = 1.0;

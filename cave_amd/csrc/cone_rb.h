@@ -1,0 +1,373 @@
+// cone_rb.h — red-black reduction of the Newton systems of band cones without bound rows (grid shortest path).
+//
+// The reduced rows of such a cone are the nodes of a graph whose edges are the coordinates (a coordinate's column holds
+// the two rows it joins); H = M W M^T is its weighted Laplacian-like matrix, and the band LDL^T pays a dependent chain
+// per row: 900 pivots for a 30 x 30 grid on one eliminator wave (cone_band.h), ~75 % of an instance's time.  An
+// INDEPENDENT set of rows R -- no two of them share a coordinate, so H_RR is diagonal: every other node of a grid --
+// needs no elimination at all:
+//     x_R = D^-1 (g_R - H_RB x_B),      (H_BB - H_BR D^-1 H_RB) x_B = g_B - H_BR D^-1 g_R,      D = diag(H_RR).
+// The Schur complement S on the other rows B keeps the half bandwidth in the order of B (two rows of a grid apart = the
+// same distance in B's numbering), so the band solver runs unchanged on HALF the rows: half the pivots of the
+// factorisation and of both substitutions, half the factor traffic.
+//
+// Taken by +-1 cones whose coordinates join at most two rows and whose rows hold at most four such coordinates.  Per call
+// (the cone is static, the weights are not): the adjacency (row -> four (coordinate, neighbour, sign) slots); R = the
+// greedy independent set by row index (row i joins when no earlier row of R is its neighbour: a checkerboard on a grid
+// in row-major order), found by parallel rounds on states in LDS; and a RECIPE for every row of S: its entries as
+// (coordinate, coordinate, red row, offset, signs) records, so that an iteration costs two memory levels per row -- the
+// records, then the weights they name -- instead of a seven-level walk through the cone.  Per Newton iteration: the
+// weights, the diagonal, the rows of S (one thread per row in a fixed order: deterministic, no atomics; staged through
+// the idle LDS ring, written to the workspace block such cones leave unused), the band solve on the black rows, the red
+// rows in closed form.
+#pragma once
+#include "cone_common.h"
+
+namespace cave {
+
+constexpr int kRbDeg = 4;  // neighbour slots per row
+
+#if defined(CAVE_GPU_CODE)
+// adjacency slot: coordinate (bit 15: sign of the product of the two entries of its column) | neighbour << 16;
+// 0xffffffff = empty
+template <class C>
+CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
+  constexpr int NT = C::NT;
+  const int p = v.p, d = v.d, ldh = w.ldh, bw = w.bw, tid = c.tid();
+  RbWork& rb = w.rb;
+  rb.on = false;
+  if (!v.pm1 || p < 8 || p > 0x7fff || d > 0x7fff) return;
+  const auto mptr = space_cast<1>(v.mptr);
+  const auto mcol = space_cast<1>(v.mcol);
+  const auto cptr = space_cast<1>(v.cptr);
+  const auto cvar = space_cast<1>(v.cvar);
+  // a coordinate joins at most two rows, a row holds at most kRbDeg coordinates
+  uint32_t bad = 0;
+  for (int k = tid; k < d; k += NT) bad += (cptr[k + 1] - cptr[k] > 2u) ? 1u : 0u;
+  for (int i = tid; i < p; i += NT) bad += (mptr[i + 1] - mptr[i] > (uint32_t)kRbDeg) ? 1u : 0u;
+  if (c.reduce_add_u32(bad) != 0u) return;
+  // ---- carve the workspace block of the (never materialised) band
+  unsigned char* base = reinterpret_cast<unsigned char*>(w.H);
+  const uint64_t room = 8ull * (uint64_t)p * (uint64_t)ldh;
+  uint64_t off = 0;
+  auto take = [&](uint64_t bytes) { unsigned char* q = base + off; off += (bytes + 15ull) & ~15ull; return q; };
+  rb.wt = reinterpret_cast<double*>(take(8ull * d));
+  rb.hd = reinterpret_cast<double*>(take(8ull * p));
+  rb.gB = reinterpret_cast<double*>(take(8ull * p));
+  rb.blk = reinterpret_cast<uint32_t*>(take(4ull * p));
+  rb.rp = reinterpret_cast<uint32_t*>(take(4ull * (p + 1)));
+  rb.radj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
+  rb.pos = reinterpret_cast<uint16_t*>(take(2ull * p));
+  rb.cls = reinterpret_cast<uint8_t*>(take(1ull * p));
+  rb.rec = reinterpret_cast<uint32_t*>(take(0));
+  // LDS (the idle ring of the band solver): states [p] bytes, then the adjacency [p][kRbDeg] words
+  const uint64_t lds_room = 8ull * band_wave_flags_at(bw);
+  const uint32_t adj_at = ((uint32_t)p + 15u) & ~15u;
+  if (off >= room || (uint64_t)adj_at + 4ull * kRbDeg * p > lds_room) return;
+  auto st = space_cast<3>(reinterpret_cast<uint8_t*>(w.bwin));
+  auto adj = space_cast<3>(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(w.bwin) + adj_at));
+  // ---- adjacency: two rows per thread in flight (extents, entries, column extents, column entries)
+  for (int i0 = tid; i0 < p; i0 += 2 * NT) {
+    uint32_t lo[2], n[2], kx[2][kRbDeg], clo[2][kRbDeg], ccnt[2][kRbDeg], x0[2][kRbDeg], x1[2][kRbDeg];
+    const uint32_t elast = mptr[p] > 0u ? mptr[p] - 1u : 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * NT;
+      const int ic = i < p ? i : p - 1;
+      lo[u] = mptr[ic];
+      n[u] = i < p ? mptr[ic + 1] - lo[u] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) kx[u][s] = mcol[lo[u] + (uint32_t)s < elast ? lo[u] + (uint32_t)s : elast];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) {
+        clo[u][s] = cptr[kx[u][s] & 0x7fffu];
+        ccnt[u][s] = cptr[(kx[u][s] & 0x7fffu) + 1u] - clo[u][s];
+      }
+    const uint32_t clast = cptr[d] > 0u ? cptr[d] - 1u : 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) {
+        x0[u][s] = cvar[clo[u][s] < clast ? clo[u][s] : clast];
+        x1[u][s] = cvar[clo[u][s] + 1u < clast ? clo[u][s] + 1u : clast];
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * NT;
+      if (i >= p) continue;
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) {
+        uint32_t slot = 0xffffffffu;
+        if ((uint32_t)s < n[u] && ccnt[u][s] == 2u) {
+          const bool first = (x0[u][s] & 0x7fffu) == (uint32_t)i;
+          const uint32_t other = (first ? x1[u][s] : x0[u][s]) & 0x7fffu;
+          const uint32_t sg = ((x0[u][s] ^ x1[u][s]) & 0x8000u);  // sign of the product of the column's two entries
+          slot = (kx[u][s] & 0x7fffu) | sg | (other << 16);
+        }
+        adj[i * kRbDeg + s] = slot;
+      }
+      st[i] = 0;
+    }
+  }
+  c.sync();
+  // ---- greedy independent set by row index, parallel rounds: a row turns black as soon as an earlier neighbour is red,
+  // red once all its earlier neighbours are black (a state only ever goes from 0 to its final value: a stale read
+  // delays a decision by a round, it never changes it)
+  for (int round = 0; round <= p; ++round) {
+    uint32_t undecided = 0;
+    for (int i = tid; i < p; i += NT) {
+      if (st[i]) continue;
+      bool wait = false, red_nb = false;
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) {
+        const uint32_t a = adj[i * kRbDeg + s];
+        const uint32_t other = a >> 16;
+        if (a == 0xffffffffu || other >= (uint32_t)i) continue;
+        const uint8_t x = st[other];
+        red_nb = red_nb || x == 1;
+        wait = wait || x == 0;
+      }
+      if (red_nb) st[i] = 2;
+      else if (!wait) st[i] = 1;
+      else ++undecided;
+    }
+    c.sync();
+    if (c.reduce_add_u32(undecided) == 0u) break;
+  }
+  const auto cls = space_cast<1>(rb.cls);
+  const auto pos = space_cast<1>(rb.pos);
+  const auto blk = space_cast<1>(rb.blk);
+  for (int i = tid; i < p; i += NT) cls[i] = st[i];
+  c.sync();
+  const int nB = (int)c.compact_mask_u8(rb.cls, p, 0xff, 2, rb.blk);
+  c.sync();
+  rb.nB = nB;
+  if (nB >= p || nB < 1 || !band_wave_fits(bw, nB) ||
+      ((uint32_t)p >= band_wave_scratch(bw)) != ((uint32_t)nB >= band_wave_scratch(bw)))
+    return;
+  for (int q = tid; q < nB; q += NT) pos[blk[q]] = (uint16_t)q;
+  c.sync();
+  // ---- recipes.  Row q of S (black row b):  a black neighbour o through coordinate k adds s w_k at column pos(o);
+  // a red neighbour r through k1, and r's neighbour o2 through k2, subtract (s1 w_k1 / D_r)(s2 w_k2) at column pos(o2)
+  // (o2 = b itself: the diagonal).  Only the columns >= q are kept (upper band).  Two passes: count, then fill.
+  const auto rp = space_cast<1>(rb.rp);
+  const auto radj = space_cast<1>(rb.radj);
+  auto walk = [&](int q, auto&& emit) {
+    const uint32_t b = blk[q];
+#pragma unroll
+    for (int s = 0; s < kRbDeg; ++s) {
+      const uint32_t a = adj[b * kRbDeg + s];
+      if (a == 0xffffffffu) continue;
+      const uint32_t o1 = a >> 16;
+      if (st[o1] == 2) {
+        const int j = (int)pos[o1];
+        if (j > q) emit(a & 0xffffu, 0xffffu, 0u, (uint32_t)(j - q), 0u);
+        continue;
+      }
+      uint32_t first = 1u;
+#pragma unroll
+      for (int s2 = 0; s2 < kRbDeg; ++s2) {
+        const uint32_t a2 = adj[o1 * kRbDeg + s2];
+        if (a2 == 0xffffffffu) continue;
+        const int j = (int)pos[a2 >> 16];
+        if (j >= q) { emit(a & 0xffffu, a2 & 0xffffu, o1, (uint32_t)(j - q), first); first = 0u; }
+      }
+    }
+  };
+  for (int q = tid; q < nB; q += NT) {
+    uint32_t cnt = 0;
+    walk(q, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { ++cnt; });
+    rp[q] = cnt;
+  }
+  if (tid == 0) rp[nB] = 0u;
+  c.sync();
+  const uint32_t nrec = c.exclusive_scan_u32(rb.rp, nB + 1);
+  rb.S = reinterpret_cast<double*>(base + ((off + 8ull * nrec + 15ull) & ~15ull));
+  if ((uint64_t)(reinterpret_cast<unsigned char*>(rb.S) - base) + 8ull * (uint64_t)nB * (uint64_t)ldh > room) return;
+  const auto rec = space_cast<1>(rb.rec);
+  double span = 0.0;
+  for (int q = tid; q < nB; q += NT) {
+    uint32_t at = rp[q];
+    walk(q, [&](uint32_t k1, uint32_t k2, uint32_t r, uint32_t offs, uint32_t first) {
+      rec[2u * at] = k1 | (k2 << 16);
+      rec[2u * at + 1u] = r | ((offs & 0xffu) << 16) | (first << 24);
+      span = fmax(span, (double)offs);
+      ++at;
+    });
+  }
+  // red rows: (coordinate | sign, position of the black neighbour) per slot
+  for (int i = tid; i < p; i += NT)
+#pragma unroll
+    for (int s = 0; s < kRbDeg; ++s) {
+      const uint32_t a = adj[i * kRbDeg + s];
+      radj[i * kRbDeg + s] = (a == 0xffffffffu || st[i] != 1) ? 0xffffffffu : ((a & 0xffffu) | ((uint32_t)pos[a >> 16] << 16));
+    }
+  const int bwS = (int)c.reduce_max(span);
+  c.sync();
+  if (bwS > bw || bwS > 255) return;
+  rb.on = true;
+}
+
+// One Newton system: (H + shift I) step = rhs, H = M W M^T with this iteration's weights (w.gen.r, w.gen.mu).
+template <class C>
+CAVE_HD void rb_solve(C& c, const SolveView& v, SolveWork& w, const double* rhs, double reg_rel) {
+  constexpr int NT = C::NT;
+  const int p = v.p, d = v.d, ldh = w.ldh, bw = w.bw, tid = c.tid();
+  const RbWork& rb = w.rb;
+  const int nB = rb.nB;
+  const auto mptr = space_cast<1>(v.mptr);
+  const auto mcol = space_cast<1>(v.mcol);
+  const auto usign = space_cast<1>(v.usign);
+  const auto cls = space_cast<1>(rb.cls);
+  const auto pos = space_cast<1>(rb.pos);
+  const auto wt = space_cast<1>(rb.wt);
+  const auto hd = space_cast<1>(rb.hd);
+  const auto S = space_cast<1>(rb.S);
+  const auto gB = space_cast<1>(rb.gB);
+  const auto rp = space_cast<1>(rb.rp);
+  const auto rec = space_cast<1>(rb.rec);
+  const auto radj = space_cast<1>(rb.radj);
+  const auto blk = space_cast<1>(rb.blk);
+  const double* r = w.gen.r;
+  const double inv_mu = w.gen.mu;
+  const double shift = reg_rel * w.gen.hdiag;
+  for (int k = tid; k < d; k += NT) wt[k] = band_weight(usign[k], r[k], inv_mu);
+  c.sync();
+  // diagonal of H + shift (entries are +-1): eight rows per thread in flight
+  {
+    constexpr int R = 8;
+    const uint32_t elast = mptr[p] > 0u ? mptr[p] - 1u : 0u;
+    for (int i0 = tid; i0 < p; i0 += R * NT) {
+      uint32_t lo[R], n[R], kx[R][kRbDeg];
+      double wk[R][kRbDeg];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int i = i0 + u * NT;
+        const int ic = i < p ? i : p - 1;
+        lo[u] = mptr[ic];
+        n[u] = i < p ? mptr[ic + 1] - lo[u] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) kx[u][s] = mcol[lo[u] + (uint32_t)s < elast ? lo[u] + (uint32_t)s : elast] & 0x7fffu;
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) wk[u][s] = wt[kx[u][s]];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int i = i0 + u * NT;
+        if (i >= p) continue;
+        double s2 = shift;
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s)
+          if ((uint32_t)s < n[u]) s2 += wk[u][s];
+        hd[i] = (cls[i] == 1) ? ((s2 > 1e-300) ? 1.0 / s2 : 0.0) : s2;
+      }
+    }
+  }
+  c.sync();
+  // rows of S and of the reduced right-hand side, RP at a time through the (idle) LDS ring of the band solver
+  auto stage = space_cast<3>(w.bwin);
+  int RP = (int)(band_wave_flags_at(bw) / (uint32_t)ldh);
+  if (RP > NT) RP = NT;
+  constexpr int EB = 6;  // records per batch: the records, then the weights they name
+  for (int q0 = 0; q0 < nB; q0 += RP) {
+    const int q = q0 + tid;
+    if (tid < RP && q < nB) {
+      auto buf = stage + tid * ldh;
+      for (int t = 0; t < ldh; ++t) buf[t] = 0.0;
+      const uint32_t b = blk[q];
+      const uint32_t e0 = rp[q], e1 = rp[q + 1];
+      double gacc = rhs[b];
+      const double hb = hd[b];
+      for (uint32_t eb = e0; eb < e1; eb += (uint32_t)EB) {
+        uint32_t w0[EB], w1[EB];
+        double a1[EB], a2[EB], dr[EB], gr[EB];
+#pragma unroll
+        for (int a = 0; a < EB; ++a) {
+          const uint32_t e = eb + (uint32_t)a < e1 ? eb + (uint32_t)a : e1 - 1u;  // clamped, unconditional
+          w0[a] = rec[2u * e];
+          w1[a] = rec[2u * e + 1u];
+        }
+#pragma unroll
+        for (int a = 0; a < EB; ++a) {
+          const uint32_t k1 = w0[a] & 0x7fffu, k2x = w0[a] >> 16, rr = w1[a] & 0xffffu;
+          a1[a] = wt[k1];
+          a2[a] = wt[k2x == 0xffffu ? k1 : (k2x & 0x7fffu)];
+          dr[a] = hd[rr];
+          gr[a] = rhs[rr];
+        }
+#pragma unroll
+        for (int a = 0; a < EB; ++a) {
+          if (eb + (uint32_t)a >= e1) break;
+          const uint32_t k2x = w0[a] >> 16, offs = (w1[a] >> 16) & 0xffu;
+          const double h1 = (w0[a] & 0x8000u) ? -a1[a] : a1[a];
+          if (k2x == 0xffffu) { buf[offs] += h1; continue; }
+          const double g = h1 * dr[a];
+          if (w1[a] >> 24) gacc -= g * gr[a];
+          buf[offs] -= g * ((k2x & 0x8000u) ? -a2[a] : a2[a]);
+        }
+      }
+      buf[0] += hb;
+      gB[q] = gacc;
+    }
+    c.sync();
+    const int nrow = nB - q0 < RP ? nB - q0 : RP;
+    for (int idx = tid; idx < nrow * ldh; idx += NT) S[q0 * ldh + idx] = stage[idx];
+    c.sync();
+  }
+  solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), rb.S, bw, rb.gB, w.act, nB, 0.0, w.bwin, w.bfac, w.bz, w.step, nullptr
+#ifdef CAVE_STAMPS
+                                 , c.st
+#endif
+  );
+  c.sync();
+  // back to the order of the reduced rows: black rows copy, red rows follow in closed form
+  for (int q = tid; q < nB; q += NT) w.bz[q] = w.step[q];
+  c.sync();
+  {
+    constexpr int R = 4;
+    for (int i0 = tid; i0 < p; i0 += R * NT) {
+      uint32_t cl[R], ps[R], ra[R][kRbDeg];
+      double hv[R], gv[R], wk[R][kRbDeg];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int ic = i0 + u * NT < p ? i0 + u * NT : p - 1;
+        cl[u] = cls[ic];
+        ps[u] = pos[ic];
+        hv[u] = hd[ic];
+        gv[u] = rhs[ic];
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) ra[u][s] = radj[ic * kRbDeg + s];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) wk[u][s] = wt[ra[u][s] == 0xffffffffu ? 0u : (ra[u][s] & 0x7fffu)];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int i = i0 + u * NT;
+        if (i >= p) continue;
+        if (cl[u] == 2) { w.step[i] = w.bz[ps[u]]; continue; }
+        double acc = gv[u];
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) {
+          if (ra[u][s] == 0xffffffffu) continue;
+          const double h = (ra[u][s] & 0x8000u) ? -wk[u][s] : wk[u][s];
+          acc -= h * w.bz[ra[u][s] >> 16];
+        }
+        w.step[i] = hv[u] * acc;
+      }
+    }
+  }
+  c.sync();
+}
+#endif
+
+}  // namespace cave

@@ -20,6 +20,7 @@ _DEPS = [
     _SRC,
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_band.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_dense.h"),
+    os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_rb.h"),
     os.path.join(_HERE, "emul", "ctx_serial.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_core.h"),
     os.path.join(_HERE, "..", "cave_amd", "csrc", "cone_common.h"),
