@@ -573,6 +573,52 @@ __device__ __forceinline__ T* uniform_ptr(T* q) {  // arguments of a real call a
 // coordinates' weights and column extents, then up to three entries of each column, are requested together -- three
 // dependent memory levels per batch instead of one per entry.  A REAL call: inlined into the elimination (which already
 // spills) the in-flight operands cost 2 ms on the 30x30 batch.
+// The same for the red-black Schur complement (cone_rb.h): row q from its RECIPE -- records (coordinate, coordinate, red
+// row, offset, signs) written once per call -- and this iteration's weights: the records of a row, then every weight
+// they name, are requested together (two memory levels per twelve records).
+__device__ __forceinline__ void band_gen_rows_rb(const RbWork* rb_v, const int lane, const int nB, const int first, const int n,
+                                                 typename SpacePtr<double, 3>::type dst, const int stride) {
+  const RbWork* rb = uniform_ptr(rb_v);
+  auto rp = space_cast<1>(uniform_ptr(rb->rp));
+  auto rec = space_cast<1>(uniform_ptr(rb->rec));
+  auto wt = space_cast<1>(uniform_ptr(rb->wt));
+  auto hd = space_cast<1>(uniform_ptr(rb->hd));
+  auto hdB = space_cast<1>(uniform_ptr(rb->hdB));
+  if (lane >= n) return;
+  const int q = first + lane;
+  auto row = dst + lane * stride;
+  for (int t = 0; t < stride; ++t) row[t] = 0.0;
+  if (q >= nB) return;
+  const uint32_t e0 = rp[q], e1 = rp[q + 1];
+  const double hb = hdB[q];
+  constexpr int EB = 12;
+  for (uint32_t eb = e0; eb < e1; eb += (uint32_t)EB) {
+    uint32_t w0[EB], w1[EB];
+    double a1[EB], a2[EB], dr[EB];
+#pragma unroll
+    for (int a = 0; a < EB; ++a) {
+      const uint32_t e = eb + (uint32_t)a < e1 ? eb + (uint32_t)a : e1 - 1u;  // clamped, unconditional
+      w0[a] = rec[2u * e];
+      w1[a] = rec[2u * e + 1u];
+    }
+#pragma unroll
+    for (int a = 0; a < EB; ++a) {
+      const uint32_t k1 = w0[a] & 0x7fffu, k2x = w0[a] >> 16;
+      a1[a] = wt[k1];
+      a2[a] = wt[k2x == 0xffffu ? k1 : (k2x & 0x7fffu)];
+      dr[a] = hd[w1[a] & 0xffffu];
+    }
+#pragma unroll
+    for (int a = 0; a < EB; ++a) {
+      const uint32_t k2x = w0[a] >> 16, offs = (w1[a] >> 16) & 0xffu;
+      const double h1 = (w0[a] & 0x8000u) ? -a1[a] : a1[a];
+      const double add = (k2x == 0xffffu) ? h1 : -(h1 * dr[a]) * ((k2x & 0x8000u) ? -a2[a] : a2[a]);
+      if (eb + (uint32_t)a < e1) row[offs] += add;
+    }
+  }
+  row[0] += hb;
+}
+
 CAVE_NOINLINE __device__ void band_gen_rows(const BandGen* gen_v, const int lane, const int p_v, const int bw_v,
                                             const int first_v, const int n_v, double* dst_v, const int stride_v) {
   const BandGen* gen = uniform_ptr(gen_v);
@@ -580,6 +626,10 @@ CAVE_NOINLINE __device__ void band_gen_rows(const BandGen* gen_v, const int lane
   const int first = __builtin_amdgcn_readfirstlane(first_v), n = __builtin_amdgcn_readfirstlane(n_v);
   const int stride = __builtin_amdgcn_readfirstlane(stride_v);
   auto dst = space_cast<3>(uniform_ptr(dst_v));
+  if (gen->rb) {  // (wave-uniform)
+    band_gen_rows_rb(gen->rb, lane, p, first, n, dst, stride);
+    return;
+  }
   auto g_mptr = space_cast<1>(uniform_ptr(gen->mptr));
   auto g_mcol = space_cast<1>(uniform_ptr(gen->mcol));
   auto g_mval = space_cast<1>(uniform_ptr(gen->mval));

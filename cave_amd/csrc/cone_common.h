@@ -210,6 +210,7 @@ CAVE_HD uint32_t tri_idx(uint32_t i, uint32_t j) {
 // The band is then never materialised: no zeroing, no atomics, no 8 p (bw + 1) bytes written and read back per
 // Newton iteration -- the elimination asks for a chunk of rows, one lane builds one row from the row's entries, the
 // smoothed weights of their coordinates and the columns of those coordinates, in a fixed order (deterministic).
+struct RbWork;
 struct BandGen {
   bool on;
   const uint32_t* mptr;   // CSR of the reduced rows
@@ -220,6 +221,7 @@ struct BandGen {
   const float* cvalc;
   const uint8_t* usign;
   const double* r;        // unclipped residual of the current iterate
+  const struct RbWork* rb = nullptr;  // rows of the red-black Schur complement instead (cone_rb.h)
   double mu;              // 1 / (smoothing scale of this iteration), 0: binary weights
   double hdiag;           // bound on the diagonal of H (largest squared row norm): scale of the Levenberg shift
 };
@@ -236,11 +238,12 @@ struct RbWork {
   uint32_t* blk;   // [nB] reduced row at position q
   double* wt;      // [d] smoothed weight of each coordinate, this iteration
   double* hd;      // [p] diagonal of H + shift (red rows: its reciprocal, 0 = dropped)
-  double* S;       // [nB * ldh] band of the Schur complement, S[q * ldh + t] = S(q, q + t)
+  double* hdB;     // [nB] the same, black rows by position
   double* gB;      // [nB] reduced right-hand side
-  uint32_t* rp;    // [nB + 1] recipe of row q of S: entries rp[q] .. rp[q + 1]
-  uint32_t* rec;   // two words per entry (cone_rb.h)
-  uint32_t* radj;  // [p * 4] red rows: their (coordinate, black neighbour) pairs
+  uint32_t* rp;    // [nB + 1] recipe of row q of S: records rp[q] .. rp[q + 1]
+  uint32_t* rec;   // two words per record (cone_rb.h)
+  uint32_t* badj;  // [nB * 4] black rows by position: their (coordinate, red neighbour) pairs
+  uint32_t* radj;  // [p * 4] red rows: their (coordinate, position of the black neighbour) pairs
 };
 
 // Dense reduced systems of the large-cone path (cone_dense.h): everything in LDS

@@ -52,18 +52,22 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   auto take = [&](uint64_t bytes) { unsigned char* q = base + off; off += (bytes + 15ull) & ~15ull; return q; };
   rb.wt = reinterpret_cast<double*>(take(8ull * d));
   rb.hd = reinterpret_cast<double*>(take(8ull * p));
+  rb.hdB = reinterpret_cast<double*>(take(8ull * p));
   rb.gB = reinterpret_cast<double*>(take(8ull * p));
   rb.blk = reinterpret_cast<uint32_t*>(take(4ull * p));
   rb.rp = reinterpret_cast<uint32_t*>(take(4ull * (p + 1)));
   rb.radj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
+  rb.badj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
   rb.pos = reinterpret_cast<uint16_t*>(take(2ull * p));
   rb.cls = reinterpret_cast<uint8_t*>(take(1ull * p));
   rb.rec = reinterpret_cast<uint32_t*>(take(0));
-  // LDS (the idle ring of the band solver): states [p] bytes, then the adjacency [p][kRbDeg] words
+  // LDS (the idle ring of the band solver): states [p] bytes, positions [p] halfwords, the adjacency [p][kRbDeg] words
   const uint64_t lds_room = 8ull * band_wave_flags_at(bw);
-  const uint32_t adj_at = ((uint32_t)p + 15u) & ~15u;
+  const uint32_t pos_at = ((uint32_t)p + 15u) & ~15u;
+  const uint32_t adj_at = (pos_at + 2u * (uint32_t)p + 15u) & ~15u;
   if (off >= room || (uint64_t)adj_at + 4ull * kRbDeg * p > lds_room) return;
   auto st = space_cast<3>(reinterpret_cast<uint8_t*>(w.bwin));
+  auto lpos = space_cast<3>(reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(w.bwin) + pos_at));
   auto adj = space_cast<3>(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(w.bwin) + adj_at));
   // ---- adjacency: two rows per thread in flight (extents, entries, column extents, column entries)
   for (int i0 = tid; i0 < p; i0 += 2 * NT) {
@@ -149,7 +153,11 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   if (nB >= p || nB < 1 || !band_wave_fits(bw, nB) ||
       ((uint32_t)p >= band_wave_scratch(bw)) != ((uint32_t)nB >= band_wave_scratch(bw)))
     return;
-  for (int q = tid; q < nB; q += NT) pos[blk[q]] = (uint16_t)q;
+  for (int q = tid; q < nB; q += NT) {
+    const uint32_t b = blk[q];
+    pos[b] = (uint16_t)q;
+    lpos[b] = (uint16_t)q;
+  }
   c.sync();
   // ---- recipes.  Row q of S (black row b):  a black neighbour o through coordinate k adds s w_k at column pos(o);
   // a red neighbour r through k1, and r's neighbour o2 through k2, subtract (s1 w_k1 / D_r)(s2 w_k2) at column pos(o2)
@@ -164,7 +172,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
       if (a == 0xffffffffu) continue;
       const uint32_t o1 = a >> 16;
       if (st[o1] == 2) {
-        const int j = (int)pos[o1];
+        const int j = (int)lpos[o1];
         if (j > q) emit(a & 0xffffu, 0xffffu, 0u, (uint32_t)(j - q), 0u);
         continue;
       }
@@ -173,7 +181,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
       for (int s2 = 0; s2 < kRbDeg; ++s2) {
         const uint32_t a2 = adj[o1 * kRbDeg + s2];
         if (a2 == 0xffffffffu) continue;
-        const int j = (int)pos[a2 >> 16];
+        const int j = (int)lpos[a2 >> 16];
         if (j >= q) { emit(a & 0xffffu, a2 & 0xffffu, o1, (uint32_t)(j - q), first); first = 0u; }
       }
     }
@@ -186,8 +194,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   if (tid == 0) rp[nB] = 0u;
   c.sync();
   const uint32_t nrec = c.exclusive_scan_u32(rb.rp, nB + 1);
-  rb.S = reinterpret_cast<double*>(base + ((off + 8ull * nrec + 15ull) & ~15ull));
-  if ((uint64_t)(reinterpret_cast<unsigned char*>(rb.S) - base) + 8ull * (uint64_t)nB * (uint64_t)ldh > room) return;
+  if (off + 8ull * (uint64_t)nrec > room) return;
   const auto rec = space_cast<1>(rb.rec);
   double span = 0.0;
   for (int q = tid; q < nB; q += NT) {
@@ -204,8 +211,18 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
 #pragma unroll
     for (int s = 0; s < kRbDeg; ++s) {
       const uint32_t a = adj[i * kRbDeg + s];
-      radj[i * kRbDeg + s] = (a == 0xffffffffu || st[i] != 1) ? 0xffffffffu : ((a & 0xffffu) | ((uint32_t)pos[a >> 16] << 16));
+      radj[i * kRbDeg + s] = (a == 0xffffffffu || st[i] != 1) ? 0xffffffffu : ((a & 0xffffu) | ((uint32_t)lpos[a >> 16] << 16));
     }
+  // black rows by position: (coordinate | sign, red neighbour) per slot
+  const auto badj = space_cast<1>(rb.badj);
+  for (int q = tid; q < nB; q += NT) {
+    const uint32_t b = blk[q];
+#pragma unroll
+    for (int s = 0; s < kRbDeg; ++s) {
+      const uint32_t a = adj[b * kRbDeg + s];
+      badj[q * kRbDeg + s] = (a == 0xffffffffu || st[a >> 16] != 1) ? 0xffffffffu : a;
+    }
+  }
   const int bwS = (int)c.reduce_max(span);
   c.sync();
   if (bwS > bw || bwS > 255) return;
@@ -226,23 +243,37 @@ CAVE_HD void rb_solve(C& c, const SolveView& v, SolveWork& w, const double* rhs,
   const auto pos = space_cast<1>(rb.pos);
   const auto wt = space_cast<1>(rb.wt);
   const auto hd = space_cast<1>(rb.hd);
-  const auto S = space_cast<1>(rb.S);
+  const auto hdB = space_cast<1>(rb.hdB);
+  const auto badj = space_cast<1>(rb.badj);
   const auto gB = space_cast<1>(rb.gB);
-  const auto rp = space_cast<1>(rb.rp);
-  const auto rec = space_cast<1>(rb.rec);
   const auto radj = space_cast<1>(rb.radj);
   const auto blk = space_cast<1>(rb.blk);
   const double* r = w.gen.r;
   const double inv_mu = w.gen.mu;
   const double shift = reg_rel * w.gen.hdiag;
-  for (int k = tid; k < d; k += NT) wt[k] = band_weight(usign[k], r[k], inv_mu);
+  {  // weights: eight coordinates per thread in flight
+    constexpr int R = 8;
+    for (int k0 = tid; k0 < d; k0 += R * NT) {
+      uint8_t us[R];
+      double rk[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int kc = k0 + u * NT < d ? k0 + u * NT : d - 1;
+        us[u] = usign[kc];
+        rk[u] = r[kc];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+        if (k0 + u * NT < d) wt[k0 + u * NT] = band_weight(us[u], rk[u], inv_mu);
+    }
+  }
   c.sync();
   // diagonal of H + shift (entries are +-1): eight rows per thread in flight
   {
     constexpr int R = 8;
     const uint32_t elast = mptr[p] > 0u ? mptr[p] - 1u : 0u;
     for (int i0 = tid; i0 < p; i0 += R * NT) {
-      uint32_t lo[R], n[R], kx[R][kRbDeg];
+      uint32_t lo[R], n[R], kx[R][kRbDeg], cl[R], ps[R];
       double wk[R][kRbDeg];
 #pragma unroll
       for (int u = 0; u < R; ++u) {
@@ -250,6 +281,8 @@ CAVE_HD void rb_solve(C& c, const SolveView& v, SolveWork& w, const double* rhs,
         const int ic = i < p ? i : p - 1;
         lo[u] = mptr[ic];
         n[u] = i < p ? mptr[ic + 1] - lo[u] : 0u;
+        cl[u] = cls[ic];
+        ps[u] = pos[ic];
       }
 #pragma unroll
       for (int u = 0; u < R; ++u)
@@ -267,62 +300,57 @@ CAVE_HD void rb_solve(C& c, const SolveView& v, SolveWork& w, const double* rhs,
 #pragma unroll
         for (int s = 0; s < kRbDeg; ++s)
           if ((uint32_t)s < n[u]) s2 += wk[u][s];
-        hd[i] = (cls[i] == 1) ? ((s2 > 1e-300) ? 1.0 / s2 : 0.0) : s2;
+        if (cl[u] == 1) hd[i] = (s2 > 1e-300) ? 1.0 / s2 : 0.0;
+        else { hd[i] = s2; hdB[ps[u]] = s2; }
       }
     }
   }
   c.sync();
-  // rows of S and of the reduced right-hand side, RP at a time through the (idle) LDS ring of the band solver
-  auto stage = space_cast<3>(w.bwin);
-  int RP = (int)(band_wave_flags_at(bw) / (uint32_t)ldh);
-  if (RP > NT) RP = NT;
-  constexpr int EB = 6;  // records per batch: the records, then the weights they name
-  for (int q0 = 0; q0 < nB; q0 += RP) {
-    const int q = q0 + tid;
-    if (tid < RP && q < nB) {
-      auto buf = stage + tid * ldh;
-      for (int t = 0; t < ldh; ++t) buf[t] = 0.0;
-      const uint32_t b = blk[q];
-      const uint32_t e0 = rp[q], e1 = rp[q + 1];
-      double gacc = rhs[b];
-      const double hb = hd[b];
-      for (uint32_t eb = e0; eb < e1; eb += (uint32_t)EB) {
-        uint32_t w0[EB], w1[EB];
-        double a1[EB], a2[EB], dr[EB], gr[EB];
+  // reduced right-hand side: four rows per thread in flight
+  {
+    constexpr int R = 4;
+    for (int q0 = tid; q0 < nB; q0 += R * NT) {
+      uint32_t bb[R], ba[R][kRbDeg];
+      double g0[R], wk[R][kRbDeg], dr[R][kRbDeg], gr[R][kRbDeg];
 #pragma unroll
-        for (int a = 0; a < EB; ++a) {
-          const uint32_t e = eb + (uint32_t)a < e1 ? eb + (uint32_t)a : e1 - 1u;  // clamped, unconditional
-          w0[a] = rec[2u * e];
-          w1[a] = rec[2u * e + 1u];
-        }
+      for (int u = 0; u < R; ++u) {
+        const int qc = q0 + u * NT < nB ? q0 + u * NT : nB - 1;
+        bb[u] = blk[qc];
 #pragma unroll
-        for (int a = 0; a < EB; ++a) {
-          const uint32_t k1 = w0[a] & 0x7fffu, k2x = w0[a] >> 16, rr = w1[a] & 0xffffu;
-          a1[a] = wt[k1];
-          a2[a] = wt[k2x == 0xffffu ? k1 : (k2x & 0x7fffu)];
-          dr[a] = hd[rr];
-          gr[a] = rhs[rr];
-        }
+        for (int s = 0; s < kRbDeg; ++s) ba[u][s] = badj[qc * kRbDeg + s];
+      }
 #pragma unroll
-        for (int a = 0; a < EB; ++a) {
-          if (eb + (uint32_t)a >= e1) break;
-          const uint32_t k2x = w0[a] >> 16, offs = (w1[a] >> 16) & 0xffu;
-          const double h1 = (w0[a] & 0x8000u) ? -a1[a] : a1[a];
-          if (k2x == 0xffffu) { buf[offs] += h1; continue; }
-          const double g = h1 * dr[a];
-          if (w1[a] >> 24) gacc -= g * gr[a];
-          buf[offs] -= g * ((k2x & 0x8000u) ? -a2[a] : a2[a]);
+      for (int u = 0; u < R; ++u) {
+        g0[u] = rhs[bb[u]];
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) {
+          const bool on = ba[u][s] != 0xffffffffu;
+          const uint32_t k1 = on ? (ba[u][s] & 0x7fffu) : 0u, rr = on ? (ba[u][s] >> 16) : 0u;
+          wk[u][s] = wt[k1];
+          dr[u][s] = hd[rr];
+          gr[u][s] = rhs[rr];
         }
       }
-      buf[0] += hb;
-      gB[q] = gacc;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int q = q0 + u * NT;
+        if (q >= nB) continue;
+        double acc = g0[u];
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) {
+          if (ba[u][s] == 0xffffffffu) continue;
+          const double h = (ba[u][s] & 0x8000u) ? -wk[u][s] : wk[u][s];
+          acc -= (h * dr[u][s]) * gr[u][s];
+        }
+        gB[q] = acc;
+      }
     }
-    c.sync();
-    const int nrow = nB - q0 < RP ? nB - q0 : RP;
-    for (int idx = tid; idx < nrow * ldh; idx += NT) S[q0 * ldh + idx] = stage[idx];
-    c.sync();
   }
-  solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), rb.S, bw, rb.gB, w.act, nB, 0.0, w.bwin, w.bfac, w.bz, w.step, nullptr
+  c.sync();
+  // the band solver on the black rows: its producer builds the rows of S from the recipes (cone_band.h band_gen_rows_rb)
+  BandGen gen = w.gen;
+  gen.rb = &w.rb;
+  solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), nullptr, bw, rb.gB, w.act, nB, 0.0, w.bwin, w.bfac, w.bz, w.step, &gen
 #ifdef CAVE_STAMPS
                                  , c.st
 #endif
