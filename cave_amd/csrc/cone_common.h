@@ -109,6 +109,30 @@ struct CtxLocal {
   CAVE_HD ~CtxLocal() { ref = c; }
 };
 
+// for i = tid, tid + NT, ... < n:  op(i, ld(i)) -- with the loads of R iterations issued before the first op.  On the
+// large-cone path the vectors live in the global workspace and a plain strided loop pays a full memory latency per
+// iteration (seven for a 900-row vector on 128 threads; the stamp build of round 4 put ~150 such latencies into one
+// Newton iteration of a 30 x 30 grid outside its band solve).  ld must be free of side effects (it is also called
+// with the clamped index n - 1); per thread the order of the ops is that of the plain loop, so the bits are the same.
+template <int R, int NT, class Ld, class Op>
+CAVE_HD void strided_batched(int tid, int n, Ld&& ld, Op&& op) {
+  if constexpr (R <= 1) {
+    for (int i = tid; i < n; i += NT) op(i, ld(i));
+  } else {
+    for (int i0 = tid; i0 < n; i0 += R * NT) {
+      decltype(ld(0)) vals[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) vals[u] = ld(i0 + u * NT < n ? i0 + u * NT : n - 1);
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+        if (i0 + u * NT < n) op(i0 + u * NT, vals[u]);
+    }
+  }
+}
+struct Ld2 { double a, b; };
+struct Ld3 { double a, b, c; };
+struct Ld4 { double a, b, c, d; };
+
 // per-instance status codes (also in include/cave_hip.h)
 enum : int32_t {
   ST_OK = 0,

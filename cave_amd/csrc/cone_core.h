@@ -411,14 +411,15 @@ CAVE_HD void gather_mt(C& c, const SolveView& v, const float* base, const double
 }
 
 // rc = Pi(r);  returns 1/2 || rc ||^2
-template <class C>
+template <class C, int R = 1>
 CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double* rc) {
   double acc = 0.0;
-  for (int k = c.tid(); k < v.d; k += C::NT) {
-    double t = clip_unit(r[k], v.usign[k]);
-    rc[k] = t;
-    acc += t * t;
-  }
+  strided_batched<R, C::NT>(c.tid(), v.d, [&](int k) { return Ld2{r[k], (double)v.usign[k]}; },
+                            [&](int k, const Ld2& x) {
+                              const double t = clip_unit(x.a, (uint8_t)x.b);
+                              rc[k] = t;
+                              acc += t * t;
+                            });
   double f = 0.5 * c.reduce_sum(acc);
   c.sync();
   return f;
@@ -814,32 +815,35 @@ __device__ __forceinline__ bool lite_model_step(C& c, const SolveView& v, SolveW
 #endif  // CAVE_GPU_CODE
 
 // phi'(alpha) and phi''(alpha) of phi(alpha) = 1/2 || Pi(r - alpha q) ||^2
-template <class C>
+template <class C, int R = 1>
 CAVE_HD void dphi(C& c, const SolveView& v, const double* r, const double* q, double alpha, double* d1, double* d2) {
   double a1 = 0.0, a2 = 0.0;
-  for (int k = c.tid(); k < v.d; k += C::NT) {
-    double qk = q[k];
-    const double rr = r[k] - alpha * qk;
-    a1 -= clip_unit(rr, v.usign[k]) * qk;
-    if (active_unit(rr, v.usign[k])) a2 += qk * qk;
-  }
+  strided_batched<R, C::NT>(c.tid(), v.d, [&](int k) { return Ld3{q[k], r[k], (double)v.usign[k]}; },
+                            [&](int, const Ld3& x) {
+                              const double qk = x.a;
+                              const double rr = x.b - alpha * qk;
+                              const uint8_t u = (uint8_t)x.c;
+                              a1 -= clip_unit(rr, u) * qk;
+                              if (active_unit(rr, u)) a2 += qk * qk;
+                            });
   *d1 = c.reduce_sum(a1);
   *d2 = c.reduce_sum(a2);
 }
 
 // theta += alpha * dv with exact zeros for variables parked at / blocked by a bound
-template <class C>
+template <class C, int R = 1>
 CAVE_HD void update_theta(C& c, const SolveView& v, double* theta, const double* tc, const double* dv, double alpha,
                           double amax) {
-  for (int i = c.tid(); i < v.p; i += C::NT) {
-    double t = theta[i] + alpha * dv[i];
-    if (!v.vkind[i]) {
-      if ((alpha == 1.0 && tc[i] == 0.0) || t < 0.0 ||
-          (alpha >= amax && dv[i] < 0.0 && theta[i] <= -amax * dv[i] * (1.0 + 1e-12)))
-        t = 0.0;
-    }
-    theta[i] = t;
-  }
+  strided_batched<R, C::NT>(c.tid(), v.p, [&](int i) { return Ld4{theta[i], dv[i], tc[i], (double)v.vkind[i]}; },
+                            [&](int i, const Ld4& x) {
+                              double t = x.a + alpha * x.b;
+                              if (x.d == 0.0) {
+                                if ((alpha == 1.0 && x.c == 0.0) || t < 0.0 ||
+                                    (alpha >= amax && x.b < 0.0 && x.a <= -amax * x.b * (1.0 + 1e-12)))
+                                  t = 0.0;
+                              }
+                              theta[i] = t;
+                            });
   c.sync();
 }
 
@@ -1193,6 +1197,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   // Starting point: theta = 0, or (warm start) the multipliers a previous solve of the SAME cone ended with --
   // cones are static per instance and predictions drift slowly during training (src/dataset.py:72), so the old
   // active set is nearly right.  The projection is unique, so the result does not depend on the start.
+  constexpr int RB = BAND ? 8 : 1;  // iterations of a strided loop whose loads are issued together (strided_batched)
   const bool warm = w.warm != nullptr;
   for (int i = c.tid(); i < p; i += NT) {
     double t0 = warm ? (double)w.warm[i] : 0.0;
@@ -1200,15 +1205,15 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     theta[i] = t0;
   }
   double yy = 0.0, ymax = 0.0;
-  for (int k = c.tid(); k < d; k += NT) {
-    yy += (double)w.y[k] * (double)w.y[k];
-    r[k] = (double)w.y[k];
-    ymax = fmax(ymax, fabs((double)w.y[k]));
-  }
+  strided_batched<RB, C::NT>(c.tid(), d, [&](int k) { return (double)w.y[k]; }, [&](int k, double yk) {
+    yy += yk * yk;
+    r[k] = yk;
+    ymax = fmax(ymax, fabs(yk));
+  });
   yy = c.reduce_sum(yy);
   ymax = c.reduce_max(ymax);
   c.sync();
-  double f = refresh_clipped(c, v, r, rc);
+  double f = refresh_clipped<C, RB>(c, v, r, rc);
   // Rounding floor of the gradient test: g_i = -sum_k m_ik rc_k is a sum of terms of size up to |m_ik| max|y|, so a
   // projected gradient below a few ulps of (largest row 1-norm) * max|y| is zero to working precision.  Without it a
   // start that is already optimal to the float32 resolution of y (y in the polar of the cone: g0n ~ 6e-8) asked for
@@ -1254,7 +1259,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     for (int i = c.tid(); i < p; i += NT) gm = fmax(gm, fabs(v.vkind[i] ? w.g[i] : fmin(w.g[i], 0.0)));
     g0n = c.reduce_max(gm);
     gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
-    f = refresh_clipped(c, v, r, rc);
+    f = refresh_clipped<C, RB>(c, v, r, rc);
   }
   const int ldh = w.ldh;
   bool dense_on = false;
@@ -1300,7 +1305,7 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         c.sync();
         if (psi0 < 0.0 && amax > 0.0) {
           gather_any<C, PM1, BAND>(c, v, nullptr, w.dv, 1.0, w.q);
-          const double alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
+          const double alpha = exact_step([&](double a, double& d1, double& d2) { dphi<C, RB>(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
           for (int i = c.tid(); i < p; i += NT) {
             double t = theta[i] + alpha * w.dv[i];
             if (!v.vkind[i] && t < 0.0) t = 0.0;
@@ -1308,20 +1313,20 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           }
           c.sync();
           gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
-          f = refresh_clipped(c, v, r, rc);
+          f = refresh_clipped<C, RB>(c, v, r, rc);
           gradient_any<C, PM1, BAND>(c, v, rc, w.g);
         }
       }
-      for (int i = c.tid(); i < p; i += NT) w.told[i] = theta[i];
+      strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return theta[i]; }, [&](int i, double t) { w.told[i] = t; });
       c.sync();
     }
     CAVE_ACCF(17);
     double pgmax = 0.0;
-    for (int i = c.tid(); i < p; i += NT) {
-      double gi = w.g[i];
-      double pg = (v.vkind[i] || theta[i] > 0.0) ? gi : fmin(gi, 0.0);
-      pgmax = fmax(pgmax, fabs(pg));
-    }
+    strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return Ld3{w.g[i], theta[i], (double)v.vkind[i]}; },
+                               [&](int, const Ld3& x) {
+                                 const double pg = (x.c != 0.0 || x.b > 0.0) ? x.a : fmin(x.a, 0.0);
+                                 pgmax = fmax(pgmax, fabs(pg));
+                               });
     double pgn = c.reduce_max(pgmax);
     if (it == 0 && !(warm && g0n > 0.0)) g0n = pgn;
 #ifdef CAVE_TRACE
@@ -1527,19 +1532,21 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         gmin = -c.reduce_max(-gl);
         if (!(gmin < 0.0)) break;
       }
-      for (int i = c.tid(); i < p; i += NT) {
-        bool at_bound = !v.vkind[i] && theta[i] <= 0.0;
-        bool release = attempt == 0 ? (w.g[i] < 0.0) : (w.g[i] <= gmin);
-        w.act[i] = (uint8_t)((at_bound && !release) ? 1 : 0);
-        tc[i] = theta[i];
-        w.dv[i] = w.g[i];  // dv doubles as the model gradient at tc
-      }
+      strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return Ld3{theta[i], w.g[i], (double)v.vkind[i]}; },
+                                 [&](int i, const Ld3& x) {
+                                   const bool at_bound = x.c == 0.0 && x.a <= 0.0;
+                                   const bool release = attempt == 0 ? (x.b < 0.0) : (x.b <= gmin);
+                                   w.act[i] = (uint8_t)((at_bound && !release) ? 1 : 0);
+                                   tc[i] = x.a;
+                                   w.dv[i] = x.b;  // dv doubles as the model gradient at tc
+                                 });
       c.sync();
       CAVE_ACCF(18);
       for (int inner = 0; inner <= p; ++inner) {
         // rhs: -model gradient on free rows, "go to zero" on fixed rows
         double* rhs = w.g2;
-        for (int i = c.tid(); i < p; i += NT) rhs[i] = w.act[i] ? -tc[i] : -w.dv[i];
+        strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return Ld3{(double)w.act[i], tc[i], w.dv[i]}; },
+                                   [&](int i, const Ld3& x) { rhs[i] = x.a != 0.0 ? -x.b : -x.c; });
         c.sync();
         CAVE_ACC(4);
         if constexpr (BAND) {
@@ -1570,12 +1577,13 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
         CAVE_ACC(5);
         // ratio test to the first blocking bound
         double amin = 2.0;
-        for (int i = c.tid(); i < p; i += NT) {
-          if (!v.vkind[i] && !w.act[i]) {
-            double t = tc[i] + w.step[i];
-            if (t < 0.0) amin = fmin(amin, tc[i] / (tc[i] - t));
-          }
-        }
+        strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return Ld4{(double)v.vkind[i], (double)w.act[i], tc[i], w.step[i]}; },
+                                   [&](int, const Ld4& x) {
+                                     if (x.a == 0.0 && x.b == 0.0) {
+                                       const double t = x.c + x.d;
+                                       if (t < 0.0) amin = fmin(amin, x.c / (x.c - t));
+                                     }
+                                   });
         amin = -c.reduce_max(-amin);
         CAVE_ACCF(19);
         const bool blocked = amin < 1.0;
@@ -1601,35 +1609,42 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
           }
           c.sync();
         }
-        for (int i = c.tid(); i < p; i += NT) {
-          double t = tc[i] + w.step[i];
-          double tn = tc[i] + a * w.step[i];
-          if (!v.vkind[i] && !w.act[i] && blocked && t < 0.0 && tc[i] <= a * (tc[i] - t) * (1.0 + 1e-12)) {
-            tn = 0.0;
-            w.act[i] = 1;
-          }
-          if (w.act[i]) tn = 0.0;
-          tc[i] = tn;
-          if (blocked) w.dv[i] += a * rhs[i];
-        }
+        struct LdU { double tc, st, vk, act, dv, rh; };
+        strided_batched<RB, C::NT>(c.tid(), p,
+                                   [&](int i) { return LdU{tc[i], w.step[i], (double)v.vkind[i], (double)w.act[i], w.dv[i], rhs[i]}; },
+                                   [&](int i, const LdU& x) {
+                                     const double t = x.tc + x.st;
+                                     double tn = x.tc + a * x.st;
+                                     bool act = x.act != 0.0;
+                                     if (x.vk == 0.0 && !act && blocked && t < 0.0 && x.tc <= a * (x.tc - t) * (1.0 + 1e-12)) {
+                                       tn = 0.0;
+                                       act = true;
+                                       w.act[i] = 1;
+                                     }
+                                     if (act) tn = 0.0;
+                                     tc[i] = tn;
+                                     if (blocked) w.dv[i] = x.dv + a * x.rh;
+                                   });
         c.sync();
         CAVE_ACCF(20);
         if (!blocked) break;
       }
       double mv = 0.0;
-      for (int i = c.tid(); i < p; i += NT) mv = fmax(mv, fabs(tc[i] - theta[i]));
+      strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return Ld2{tc[i], theta[i]}; },
+                                 [&](int, const Ld2& x) { mv = fmax(mv, fabs(x.a - x.b)); });
       moved = c.reduce_max(mv) > 0.0;
     }
     CAVE_ACC(4);
     if (!moved) { converged = !(pgn > 1e-6 * g0n) || pgn <= gfloor; break; }
     // ---- exact line search on the true f along dv = tc - theta
     double psi0 = 0.0, amax = 1e300;
-    for (int i = c.tid(); i < p; i += NT) {
-      double di = tc[i] - theta[i];
-      w.dv[i] = di;
-      psi0 += w.g[i] * di;
-      if (!v.vkind[i] && di < 0.0) amax = fmin(amax, theta[i] / (-di));
-    }
+    strided_batched<RB, C::NT>(c.tid(), p, [&](int i) { return Ld4{tc[i], theta[i], w.g[i], (double)v.vkind[i]}; },
+                               [&](int i, const Ld4& x) {
+                                 const double di = x.a - x.b;
+                                 w.dv[i] = di;
+                                 psi0 += x.c * di;
+                                 if (x.d == 0.0 && di < 0.0) amax = fmin(amax, x.b / (-di));
+                               });
     if constexpr (ctx_lite<C>::value) {  // one interleaved pass for both
       double nm = -amax;
       c.reduce_sum_max(psi0, nm);
@@ -1713,15 +1728,16 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
     } else {
       gather_any<C, PM1, BAND>(c, v, nullptr, w.dv, 1.0, w.q);
       CAVE_ACC(6);
-      alpha = exact_step([&](double a, double& d1, double& d2) { dphi(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
-      update_theta(c, v, theta, tc, w.dv, alpha, amax);
+      alpha = exact_step([&](double a, double& d1, double& d2) { dphi<C, RB>(c, v, r, w.q, a, &d1, &d2); }, psi0, amax);
+      update_theta<C, RB>(c, v, theta, tc, w.dv, alpha, amax);
       CAVE_ACC(7);
       if ((it & 7) == 7) gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
       else {
-        for (int k = c.tid(); k < d; k += NT) r[k] -= alpha * w.q[k];
+        strided_batched<RB, C::NT>(c.tid(), d, [&](int k) { return Ld2{r[k], w.q[k]}; },
+                                   [&](int k, const Ld2& x) { r[k] = x.a - alpha * x.b; });
         c.sync();
       }
-      fn = refresh_clipped(c, v, r, rc);
+      fn = refresh_clipped<C, RB>(c, v, r, rc);
       CAVE_ACC(8);
     }
     // An exact line search along the Newton direction that no longer lowers f beyond
@@ -1744,9 +1760,9 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
   // final residual straight from theta (the iteration updated r incrementally), clipped for the epilogue
   if (p > 0) {
     gather_any<C, PM1, BAND>(c, v, w.y, theta, -1.0, r);
-    f = refresh_clipped(c, v, r, rc);
+    f = refresh_clipped<C, RB>(c, v, r, rc);
   }
-  for (int k = c.tid(); k < d; k += NT) r[k] = rc[k];
+  strided_batched<RB, C::NT>(c.tid(), d, [&](int k) { return rc[k]; }, [&](int k, double t) { r[k] = t; });
   c.sync();
   if (!converged) out.status = ST_NOT_CONVERGED;
   if (!(f == f) || !(yy == yy)) out.status = ST_BAD_INPUT;
