@@ -41,9 +41,13 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   const auto cptr = space_cast<1>(v.cptr);
   const auto cvar = space_cast<1>(v.cvar);
   // a coordinate joins at most two rows, a row holds at most kRbDeg coordinates
+  if (p > 32 * NT) return;  // (a thread keeps its undecided rows in one word below)
   uint32_t bad = 0;
-  for (int k = tid; k < d; k += NT) bad += (cptr[k + 1] - cptr[k] > 2u) ? 1u : 0u;
-  for (int i = tid; i < p; i += NT) bad += (mptr[i + 1] - mptr[i] > (uint32_t)kRbDeg) ? 1u : 0u;
+  struct LdE { uint32_t lo, hi; };
+  strided_batched<8, NT>(tid, d, [&](int k) { return LdE{cptr[k], cptr[k + 1]}; },
+                         [&](int, const LdE& x) { bad += (x.hi - x.lo > 2u) ? 1u : 0u; });
+  strided_batched<8, NT>(tid, p, [&](int i) { return LdE{mptr[i], mptr[i + 1]}; },
+                         [&](int, const LdE& x) { bad += (x.hi - x.lo > (uint32_t)kRbDeg) ? 1u : 0u; });
   if (c.reduce_add_u32(bad) != 0u) return;
   // ---- carve the workspace block of the (never materialised) band
   unsigned char* base = reinterpret_cast<unsigned char*>(w.H);
@@ -61,31 +65,39 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   rb.pos = reinterpret_cast<uint16_t*>(take(2ull * p));
   rb.cls = reinterpret_cast<uint8_t*>(take(1ull * p));
   rb.rec = reinterpret_cast<uint32_t*>(take(0));
-  // LDS (the idle ring of the band solver): states [p] bytes, positions [p] halfwords, the adjacency [p][kRbDeg] words
+  // LDS (the idle ring of the band solver): states [p] bytes, positions and black rows [p] halfwords each, the adjacency
+  // [p][kRbDeg] words, row pointers of the recipes [p + 1] words (first the compacted list of black rows) -- everything
+  // the set-up walks more than once; the workspace only receives the results
   const uint64_t lds_room = 8ull * band_wave_flags_at(bw);
   const uint32_t pos_at = ((uint32_t)p + 15u) & ~15u;
-  const uint32_t adj_at = (pos_at + 2u * (uint32_t)p + 15u) & ~15u;
-  if (off >= room || (uint64_t)adj_at + 4ull * kRbDeg * p > lds_room) return;
-  auto st = space_cast<3>(reinterpret_cast<uint8_t*>(w.bwin));
-  auto lpos = space_cast<3>(reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(w.bwin) + pos_at));
-  auto adj = space_cast<3>(reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(w.bwin) + adj_at));
-  // ---- adjacency: two rows per thread in flight (extents, entries, column extents, column entries)
-  for (int i0 = tid; i0 < p; i0 += 2 * NT) {
-    uint32_t lo[2], n[2], kx[2][kRbDeg], clo[2][kRbDeg], ccnt[2][kRbDeg], x0[2][kRbDeg], x1[2][kRbDeg];
+  const uint32_t blk_at = (pos_at + 2u * (uint32_t)p + 15u) & ~15u;
+  const uint32_t adj_at = (blk_at + 2u * (uint32_t)p + 15u) & ~15u;
+  const uint32_t rp_at = adj_at + 4u * kRbDeg * (uint32_t)p;
+  if (off >= room || (uint64_t)rp_at + 4ull * (p + 1) > lds_room) return;
+  unsigned char* lbase = reinterpret_cast<unsigned char*>(w.bwin);
+  auto st = space_cast<3>(reinterpret_cast<uint8_t*>(lbase));
+  auto lpos = space_cast<3>(reinterpret_cast<uint16_t*>(lbase + pos_at));
+  auto lblk = space_cast<3>(reinterpret_cast<uint16_t*>(lbase + blk_at));
+  auto adj = space_cast<3>(reinterpret_cast<uint32_t*>(lbase + adj_at));
+  auto lrp = space_cast<3>(reinterpret_cast<uint32_t*>(lbase + rp_at));
+  // ---- adjacency: four rows per thread in flight (extents, entries, column extents, column entries)
+  constexpr int RA = 4;
+  for (int i0 = tid; i0 < p; i0 += RA * NT) {
+    uint32_t lo[RA], n[RA], kx[RA][kRbDeg], clo[RA][kRbDeg], ccnt[RA][kRbDeg], x0[RA][kRbDeg], x1[RA][kRbDeg];
     const uint32_t elast = mptr[p] > 0u ? mptr[p] - 1u : 0u;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RA; ++u) {
       const int i = i0 + u * NT;
       const int ic = i < p ? i : p - 1;
       lo[u] = mptr[ic];
       n[u] = i < p ? mptr[ic + 1] - lo[u] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < RA; ++u)
 #pragma unroll
       for (int s = 0; s < kRbDeg; ++s) kx[u][s] = mcol[lo[u] + (uint32_t)s < elast ? lo[u] + (uint32_t)s : elast];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < RA; ++u)
 #pragma unroll
       for (int s = 0; s < kRbDeg; ++s) {
         clo[u][s] = cptr[kx[u][s] & 0x7fffu];
@@ -93,14 +105,14 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
       }
     const uint32_t clast = cptr[d] > 0u ? cptr[d] - 1u : 0u;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < RA; ++u)
 #pragma unroll
       for (int s = 0; s < kRbDeg; ++s) {
         x0[u][s] = cvar[clo[u][s] < clast ? clo[u][s] : clast];
         x1[u][s] = cvar[clo[u][s] + 1u < clast ? clo[u][s] + 1u : clast];
       }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RA; ++u) {
       const int i = i0 + u * NT;
       if (i >= p) continue;
 #pragma unroll
@@ -121,10 +133,17 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   // ---- greedy independent set by row index, parallel rounds: a row turns black as soon as an earlier neighbour is red,
   // red once all its earlier neighbours are black (a state only ever goes from 0 to its final value: a stale read
   // delays a decision by a round, it never changes it)
-  for (int round = 0; round <= p; ++round) {
-    uint32_t undecided = 0;
-    for (int i = tid; i < p; i += NT) {
-      if (st[i]) continue;
+  // (a thread walks only the rows it has not decided yet: bit u of `open` = row tid + u * NT; on a grid a row is decided
+  // in the round its anti-diagonal comes up, so a round costs a couple of LDS reads and a barrier; whether everybody is
+  // done is asked every eighth round)
+  uint32_t open = 0;
+  for (int u = 0; u < 32; ++u) open |= (tid + u * NT < p) ? (1u << u) : 0u;
+  for (int round = 0; round <= p + 8; ++round) {
+    uint32_t m = open;
+    while (m) {
+      const int u = __builtin_ctz(m);
+      m &= m - 1u;
+      const int i = tid + u * NT;
       bool wait = false, red_nb = false;
 #pragma unroll
       for (int s = 0; s < kRbDeg; ++s) {
@@ -135,26 +154,26 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
         red_nb = red_nb || x == 1;
         wait = wait || x == 0;
       }
-      if (red_nb) st[i] = 2;
-      else if (!wait) st[i] = 1;
-      else ++undecided;
+      if (red_nb) { st[i] = 2; open &= ~(1u << u); }
+      else if (!wait) { st[i] = 1; open &= ~(1u << u); }
     }
     c.sync();
-    if (c.reduce_add_u32(undecided) == 0u) break;
+    if ((round & 7) == 7 && c.reduce_add_u32(open != 0u ? 1u : 0u) == 0u) break;
   }
   const auto cls = space_cast<1>(rb.cls);
   const auto pos = space_cast<1>(rb.pos);
   const auto blk = space_cast<1>(rb.blk);
-  for (int i = tid; i < p; i += NT) cls[i] = st[i];
-  c.sync();
-  const int nB = (int)c.compact_mask_u8(rb.cls, p, 0xff, 2, rb.blk);
+  const int nB = (int)c.compact_mask_u8(reinterpret_cast<const uint8_t*>(lbase), p, 0xff, 2, reinterpret_cast<uint32_t*>(lbase + rp_at));
   c.sync();
   rb.nB = nB;
   if (nB >= p || nB < 1 || !band_wave_fits(bw, nB) ||
       ((uint32_t)p >= band_wave_scratch(bw)) != ((uint32_t)nB >= band_wave_scratch(bw)))
     return;
+  for (int i = tid; i < p; i += NT) cls[i] = st[i];
   for (int q = tid; q < nB; q += NT) {
-    const uint32_t b = blk[q];
+    const uint32_t b = lrp[q];
+    lblk[q] = (uint16_t)b;
+    blk[q] = b;
     pos[b] = (uint16_t)q;
     lpos[b] = (uint16_t)q;
   }
@@ -165,7 +184,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   const auto rp = space_cast<1>(rb.rp);
   const auto radj = space_cast<1>(rb.radj);
   auto walk = [&](int q, auto&& emit) {
-    const uint32_t b = blk[q];
+    const uint32_t b = lblk[q];
 #pragma unroll
     for (int s = 0; s < kRbDeg; ++s) {
       const uint32_t a = adj[b * kRbDeg + s];
@@ -189,16 +208,17 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   for (int q = tid; q < nB; q += NT) {
     uint32_t cnt = 0;
     walk(q, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { ++cnt; });
-    rp[q] = cnt;
+    lrp[q] = cnt;
   }
-  if (tid == 0) rp[nB] = 0u;
+  if (tid == 0) lrp[nB] = 0u;
   c.sync();
-  const uint32_t nrec = c.exclusive_scan_u32(rb.rp, nB + 1);
+  const uint32_t nrec = c.exclusive_scan_u32(reinterpret_cast<uint32_t*>(lbase + rp_at), nB + 1);
   if (off + 8ull * (uint64_t)nrec > room) return;
+  for (int q = tid; q <= nB; q += NT) rp[q] = lrp[q];
   const auto rec = space_cast<1>(rb.rec);
   double span = 0.0;
   for (int q = tid; q < nB; q += NT) {
-    uint32_t at = rp[q];
+    uint32_t at = lrp[q];
     walk(q, [&](uint32_t k1, uint32_t k2, uint32_t r, uint32_t offs, uint32_t first) {
       rec[2u * at] = k1 | (k2 << 16);
       rec[2u * at + 1u] = r | ((offs & 0xffu) << 16) | (first << 24);
@@ -216,7 +236,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   // black rows by position: (coordinate | sign, red neighbour) per slot
   const auto badj = space_cast<1>(rb.badj);
   for (int q = tid; q < nB; q += NT) {
-    const uint32_t b = blk[q];
+    const uint32_t b = lblk[q];
 #pragma unroll
     for (int s = 0; s < kRbDeg; ++s) {
       const uint32_t a = adj[b * kRbDeg + s];
