@@ -129,7 +129,7 @@ CAVE_HD SolveView view_of(const ConeBuild& cb) {
 
 // hot-first allocation of the large-cone path: LDS while it lasts, then the global workspace
 #ifdef CAVE_EMUL_COUNTERS
-inline long* emul_counters() {  // test builds only: [0] dense path, [1] one-wave band path, [2] lite path, [3] H-free band
+inline long* emul_counters() {  // test builds only: [0] dense path, [1] one-wave band path, [2] lite path, [3] H-free band, [4] lite with bound rows, [5] red-black reduction of the band
   static long cnt[8] = {0};
   return cnt;
 }
@@ -332,7 +332,12 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
 #endif
       } else w.H = nullptr;
 #if defined(CAVE_GPU_CODE) && !defined(CAVE_NO_RB)  // (diagnostic builds can pin the full-size band)
-      if (rb_wanted && mode != MODE_IPM) rb_setup(c, v, w);
+      if (rb_wanted && mode != MODE_IPM) {
+        rb_setup(c, v, w);
+#ifdef CAVE_EMUL_COUNTERS
+        if (c.tid() == 0 && w.rb.on) ++emul_counters()[5];
+#endif
+      }
 #endif
     } else {
       w.dn.on = false;

@@ -36,12 +36,12 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   RbWork& rb = w.rb;
   rb.on = false;
   if (!v.pm1 || p < 8 || p > 0x7fff || d > 0x7fff) return;
+  if (p > 32 * NT) return;  // (a thread keeps its undecided rows in one word below)
   const auto mptr = space_cast<1>(v.mptr);
   const auto mcol = space_cast<1>(v.mcol);
   const auto cptr = space_cast<1>(v.cptr);
   const auto cvar = space_cast<1>(v.cvar);
   // a coordinate joins at most two rows, a row holds at most kRbDeg coordinates
-  if (p > 32 * NT) return;  // (a thread keeps its undecided rows in one word below)
   uint32_t bad = 0;
   struct LdE { uint32_t lo, hi; };
   strided_batched<8, NT>(tid, d, [&](int k) { return LdE{cptr[k], cptr[k + 1]}; },
@@ -62,25 +62,28 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   rb.rp = reinterpret_cast<uint32_t*>(take(4ull * (p + 1)));
   rb.radj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
   rb.badj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
+  uint32_t* adjG_ = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));  // adjacency slots (set-up only)
   rb.pos = reinterpret_cast<uint16_t*>(take(2ull * p));
   rb.cls = reinterpret_cast<uint8_t*>(take(1ull * p));
   rb.rec = reinterpret_cast<uint32_t*>(take(0));
-  // LDS (the idle ring of the band solver): states [p] bytes, positions and black rows [p] halfwords each, the adjacency
-  // [p][kRbDeg] words, row pointers of the recipes [p + 1] words (first the compacted list of black rows) -- everything
-  // the set-up walks more than once; the workspace only receives the results
+  // LDS (the idle ring of the band solver) holds what the set-up walks again and again: states [p] bytes, positions and
+  // black rows [p] halfwords each, the neighbours [p][kRbDeg] halfwords, row pointers of the recipes [p + 1] words (first
+  // the compacted list of black rows).  17 p bytes; the workspace receives the results and the full adjacency slots.
   const uint64_t lds_room = 8ull * band_wave_flags_at(bw);
   const uint32_t pos_at = ((uint32_t)p + 15u) & ~15u;
   const uint32_t blk_at = (pos_at + 2u * (uint32_t)p + 15u) & ~15u;
-  const uint32_t adj_at = (blk_at + 2u * (uint32_t)p + 15u) & ~15u;
-  const uint32_t rp_at = adj_at + 4u * kRbDeg * (uint32_t)p;
+  const uint32_t oth_at = (blk_at + 2u * (uint32_t)p + 15u) & ~15u;
+  const uint32_t rp_at = (oth_at + 2u * kRbDeg * (uint32_t)p + 15u) & ~15u;
   if (off >= room || (uint64_t)rp_at + 4ull * (p + 1) > lds_room) return;
   unsigned char* lbase = reinterpret_cast<unsigned char*>(w.bwin);
   auto st = space_cast<3>(reinterpret_cast<uint8_t*>(lbase));
   auto lpos = space_cast<3>(reinterpret_cast<uint16_t*>(lbase + pos_at));
   auto lblk = space_cast<3>(reinterpret_cast<uint16_t*>(lbase + blk_at));
-  auto adj = space_cast<3>(reinterpret_cast<uint32_t*>(lbase + adj_at));
+  auto oth = space_cast<3>(reinterpret_cast<uint16_t*>(lbase + oth_at));  // 0xffff: no neighbour in this slot
   auto lrp = space_cast<3>(reinterpret_cast<uint32_t*>(lbase + rp_at));
+  const auto adjG = space_cast<1>(adjG_);
   // ---- adjacency: four rows per thread in flight (extents, entries, column extents, column entries)
+  // slot: coordinate (bit 15: sign of the product of the two entries of its column) | neighbour << 16; 0xffffffff = empty
   constexpr int RA = 4;
   for (int i0 = tid; i0 < p; i0 += RA * NT) {
     uint32_t lo[RA], n[RA], kx[RA][kRbDeg], clo[RA][kRbDeg], ccnt[RA][kRbDeg], x0[RA][kRbDeg], x1[RA][kRbDeg];
@@ -124,7 +127,8 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
           const uint32_t sg = ((x0[u][s] ^ x1[u][s]) & 0x8000u);  // sign of the product of the column's two entries
           slot = (kx[u][s] & 0x7fffu) | sg | (other << 16);
         }
-        adj[i * kRbDeg + s] = slot;
+        adjG[i * kRbDeg + s] = slot;
+        oth[i * kRbDeg + s] = (uint16_t)(slot >> 16);
       }
       st[i] = 0;
     }
@@ -132,10 +136,9 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   c.sync();
   // ---- greedy independent set by row index, parallel rounds: a row turns black as soon as an earlier neighbour is red,
   // red once all its earlier neighbours are black (a state only ever goes from 0 to its final value: a stale read
-  // delays a decision by a round, it never changes it)
-  // (a thread walks only the rows it has not decided yet: bit u of `open` = row tid + u * NT; on a grid a row is decided
-  // in the round its anti-diagonal comes up, so a round costs a couple of LDS reads and a barrier; whether everybody is
-  // done is asked every eighth round)
+  // delays a decision by a round, it never changes it).  A thread walks only the rows it has not decided yet (bit u of
+  // `open` = row tid + u * NT): on a grid a row is decided in the round its anti-diagonal comes up, so a round costs a
+  // couple of LDS reads and a barrier; whether everybody is done is asked every eighth round.
   uint32_t open = 0;
   for (int u = 0; u < 32; ++u) open |= (tid + u * NT < p) ? (1u << u) : 0u;
   for (int round = 0; round <= p + 8; ++round) {
@@ -147,9 +150,8 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
       bool wait = false, red_nb = false;
 #pragma unroll
       for (int s = 0; s < kRbDeg; ++s) {
-        const uint32_t a = adj[i * kRbDeg + s];
-        const uint32_t other = a >> 16;
-        if (a == 0xffffffffu || other >= (uint32_t)i) continue;
+        const uint32_t other = oth[i * kRbDeg + s];
+        if (other >= (uint32_t)i) continue;  // (0xffff: empty)
         const uint8_t x = st[other];
         red_nb = red_nb || x == 1;
         wait = wait || x == 0;
@@ -180,34 +182,24 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   c.sync();
   // ---- recipes.  Row q of S (black row b):  a black neighbour o through coordinate k adds s w_k at column pos(o);
   // a red neighbour r through k1, and r's neighbour o2 through k2, subtract (s1 w_k1 / D_r)(s2 w_k2) at column pos(o2)
-  // (o2 = b itself: the diagonal).  Only the columns >= q are kept (upper band).  Two passes: count, then fill.
+  // (o2 = b itself: the diagonal).  Only the columns >= q are kept (upper band).  Counted from the LDS copies, filled from
+  // the adjacency slots (the row's, then its red neighbours': two memory levels per row).
   const auto rp = space_cast<1>(rb.rp);
   const auto radj = space_cast<1>(rb.radj);
-  auto walk = [&](int q, auto&& emit) {
+  for (int q = tid; q < nB; q += NT) {
     const uint32_t b = lblk[q];
+    uint32_t cnt = 0;
 #pragma unroll
     for (int s = 0; s < kRbDeg; ++s) {
-      const uint32_t a = adj[b * kRbDeg + s];
-      if (a == 0xffffffffu) continue;
-      const uint32_t o1 = a >> 16;
-      if (st[o1] == 2) {
-        const int j = (int)lpos[o1];
-        if (j > q) emit(a & 0xffffu, 0xffffu, 0u, (uint32_t)(j - q), 0u);
-        continue;
-      }
-      uint32_t first = 1u;
+      const uint32_t o1 = oth[b * kRbDeg + s];
+      if (o1 == 0xffffu) continue;
+      if (st[o1] == 2) { cnt += ((int)lpos[o1] > q) ? 1u : 0u; continue; }
 #pragma unroll
       for (int s2 = 0; s2 < kRbDeg; ++s2) {
-        const uint32_t a2 = adj[o1 * kRbDeg + s2];
-        if (a2 == 0xffffffffu) continue;
-        const int j = (int)lpos[a2 >> 16];
-        if (j >= q) { emit(a & 0xffffu, a2 & 0xffffu, o1, (uint32_t)(j - q), first); first = 0u; }
+        const uint32_t o2 = oth[o1 * kRbDeg + s2];
+        if (o2 != 0xffffu) cnt += ((int)lpos[o2] >= q) ? 1u : 0u;
       }
     }
-  };
-  for (int q = tid; q < nB; q += NT) {
-    uint32_t cnt = 0;
-    walk(q, [&](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { ++cnt; });
     lrp[q] = cnt;
   }
   if (tid == 0) lrp[nB] = 0u;
@@ -216,33 +208,57 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   if (off + 8ull * (uint64_t)nrec > room) return;
   for (int q = tid; q <= nB; q += NT) rp[q] = lrp[q];
   const auto rec = space_cast<1>(rb.rec);
+  const auto badj = space_cast<1>(rb.badj);
   double span = 0.0;
   for (int q = tid; q < nB; q += NT) {
-    uint32_t at = lrp[q];
-    walk(q, [&](uint32_t k1, uint32_t k2, uint32_t r, uint32_t offs, uint32_t first) {
+    const uint32_t b = lblk[q];
+    uint32_t at = lrp[q], a1[kRbDeg], a2[kRbDeg][kRbDeg];
+#pragma unroll
+    for (int s = 0; s < kRbDeg; ++s) a1[s] = adjG[b * kRbDeg + s];
+#pragma unroll
+    for (int s = 0; s < kRbDeg; ++s)
+#pragma unroll
+      for (int s2 = 0; s2 < kRbDeg; ++s2) a2[s][s2] = adjG[(a1[s] == 0xffffffffu ? b : (a1[s] >> 16)) * kRbDeg + s2];
+    auto emit = [&](uint32_t k1, uint32_t k2, uint32_t r, uint32_t offs, uint32_t first) {
       rec[2u * at] = k1 | (k2 << 16);
       rec[2u * at + 1u] = r | ((offs & 0xffu) << 16) | (first << 24);
       span = fmax(span, (double)offs);
       ++at;
-    });
+    };
+#pragma unroll
+    for (int s = 0; s < kRbDeg; ++s) {
+      const uint32_t a = a1[s];
+      const uint32_t o1 = a >> 16;
+      uint32_t bslot = 0xffffffffu;  // (coordinate | sign, red neighbour) of the black row at position q
+      if (a != 0xffffffffu) {
+        if (st[o1] == 2) {
+          const int j = (int)lpos[o1];
+          if (j > q) emit(a & 0xffffu, 0xffffu, 0u, (uint32_t)(j - q), 0u);
+        } else {
+          bslot = a;
+          uint32_t first = 1u;
+#pragma unroll
+          for (int s2 = 0; s2 < kRbDeg; ++s2) {
+            const uint32_t b2 = a2[s][s2];
+            if (b2 == 0xffffffffu) continue;
+            const int j = (int)lpos[b2 >> 16];
+            if (j >= q) { emit(a & 0xffffu, b2 & 0xffffu, o1, (uint32_t)(j - q), first); first = 0u; }
+          }
+        }
+      }
+      badj[q * kRbDeg + s] = bslot;
+    }
   }
   // red rows: (coordinate | sign, position of the black neighbour) per slot
-  for (int i = tid; i < p; i += NT)
+  struct LdA { uint32_t a[kRbDeg]; };
+  strided_batched<4, NT>(tid, p, [&](int i) { LdA x; for (int s = 0; s < kRbDeg; ++s) x.a[s] = adjG[i * kRbDeg + s]; return x; },
+                         [&](int i, const LdA& x) {
 #pragma unroll
-    for (int s = 0; s < kRbDeg; ++s) {
-      const uint32_t a = adj[i * kRbDeg + s];
-      radj[i * kRbDeg + s] = (a == 0xffffffffu || st[i] != 1) ? 0xffffffffu : ((a & 0xffffu) | ((uint32_t)lpos[a >> 16] << 16));
-    }
-  // black rows by position: (coordinate | sign, red neighbour) per slot
-  const auto badj = space_cast<1>(rb.badj);
-  for (int q = tid; q < nB; q += NT) {
-    const uint32_t b = lblk[q];
-#pragma unroll
-    for (int s = 0; s < kRbDeg; ++s) {
-      const uint32_t a = adj[b * kRbDeg + s];
-      badj[q * kRbDeg + s] = (a == 0xffffffffu || st[a >> 16] != 1) ? 0xffffffffu : a;
-    }
-  }
+                           for (int s = 0; s < kRbDeg; ++s) {
+                             const uint32_t a = x.a[s];
+                             radj[i * kRbDeg + s] = (a == 0xffffffffu || st[i] != 1) ? 0xffffffffu : ((a & 0xffffu) | ((uint32_t)lpos[a >> 16] << 16));
+                           }
+                         });
   const int bwS = (int)c.reduce_max(span);
   c.sync();
   if (bwS > bw || bwS > 255) return;

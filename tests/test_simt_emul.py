@@ -113,6 +113,35 @@ def test_band_elimination_under_emulation(emul, simt, golden, waves):
     assert simt.path_counters()[1] == 4  # the one-wave band form ran for every instance
 
 
+def test_red_black_reduction_of_the_band_under_emulation(emul, simt):
+    """cone_rb.h: a 24 x 24 grid (576 free rows, half bandwidth 24; 288 of them stay in the band system) on the two-wave
+    shape -- the adjacency, the greedy independent set, the recipes, the producer building rows of the Schur complement,
+    the closed-form red rows -- against the serial build of the same source (which has no one-wave band form and
+    therefore factors the full band), round-robin and shuffled schedules."""
+    from cave_amd import synth
+
+    c, y, _ = synth.sp_batch(24, 24, 1, seed=5)
+    st, arrs, mr, _ = emul.pack_large(c)
+    bw = store_bandwidth(arrs, 1, c.shape[2])
+    assert (mr, bw) == (576, 24)
+    ref = emul.cone_packed_large(st, arrs, mr, np.arange(1), y, MODE_PROJECT, sign=-1.0)
+    assert (ref["status"] == 0).all()
+    # what ConeStore._fold_signs does when it finalises a store of this path: the signs of an all-+-1 instance go into
+    # bit 15 of its stored indices (flags bit 1) -- the reduction takes such instances only
+    assert (arrs["flags"] & 1).all()
+    for idx, val in (("ccol", "cval"), ("cvar", "cvalc")):
+        arrs[idx] |= (arrs[val] < 0).astype(np.uint16) << 15
+    arrs["flags"] |= 2
+    sc = max(1.0, float(np.abs(y).max()))
+    simt.path_counters()
+    for seed in (0, 31):
+        o = simt.cone_packed_large(st, arrs, mr, bw, np.arange(1), y, MODE_PROJECT, sign=-1.0, waves=2, seed=seed)
+        assert (o["status"] == 0).all() and o["iters"].max() <= 14, (seed, o["iters"])
+        assert np.abs(o["proj"] - ref["proj"]).max() <= 2e-6 * sc, seed
+        assert np.abs(o["rnorm"] - ref["rnorm"]).max() <= 2e-6 * sc, seed
+    assert simt.path_counters()[5] == 2  # both runs took the reduction
+
+
 def test_diet_layout_of_the_packed_operator_under_emulation(emul, simt, golden):
     """cone_packed_kernel<BlockCtx<4, true>> with the "diet" LDS layout (round 4: TSP-50 at two workgroups per compute
     unit -- H as a packed lower triangle, CSC entries and average normal read in place from the store, batched column
