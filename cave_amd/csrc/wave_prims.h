@@ -243,7 +243,9 @@ __device__ __forceinline__ void gj_partial(int lane, const double* H, int ldh, c
   if (p <= 8) gj_partial_regs<8, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
   else if (p <= 16) gj_partial_regs<16, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
   else if (p <= 20) gj_partial_regs<20, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if (p <= 22) gj_partial_regs<22, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
   else if (p <= 24) gj_partial_regs<24, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
+  else if (p <= 26) gj_partial_regs<26, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
   else if (p <= 28) gj_partial_regs<28, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
   else if constexpr (PLIM >= 32) gj_partial_regs<32, LOWER>(lane, H, ldh, rhs, p, nF, reg_rel, XS, xg);
 }
