@@ -1752,8 +1752,12 @@ CAVE_HD SolveResult solve_cone_impl(C& c, const SolveView& v, SolveWork& w, int 
       // (The looser gradient test is only trusted once the step has been damped to 1e-6: with the 1e-12
       // shift a Hessian of condition 1e12+ gives a direction made of round-off, and "no gain along it"
       // says nothing about optimality.)
-      if (reg_rel >= 1e-6 && !(pgn > 1e-8 * g0n)) { converged = true; ++it; break; }
-      if (reg_rel >= 1e-2) { converged = !(pgn > 1e-8 * g0n) || pgn <= gfloor; ++it; break; }
+      // (A start that is optimal up to the float32 rounding of y -- g0n ~ 1e-9 of the gradient's natural scale -- makes
+      //  the relative tests unreachable in double precision: with f stagnant along damped Newton directions, a projected
+      //  gradient within 1e3 rounding floors of zero is accepted.  tools/fuzz/fuzz_gpu.py seed 3001, round 4: a 6 x 16
+      //  +-1 cone with a duplicated row was flagged NOT_CONVERGED at pgn = 1e-12 with the projection exact to 2e-16.)
+      if (reg_rel >= 1e-6 && (!(pgn > 1e-8 * g0n) || pgn <= 1e3 * gfloor)) { converged = true; ++it; break; }
+      if (reg_rel >= 1e-2) { converged = !(pgn > 1e-8 * g0n) || pgn <= 1e3 * gfloor; ++it; break; }
       reg_rel *= 1e3;
     } else if (reg_rel > 1e-12) reg_rel *= 0.1;
   }

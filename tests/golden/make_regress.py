@@ -12,6 +12,9 @@ Inputs (fixture data, kept in the .npz itself so this script can be re-run):
             to the float32 resolution of y, the initial projected gradient is ~6e-8 and a convergence test relative
             to it alone can never be met -- the solver returned the right projection flagged NOT_CONVERGED until
             the gradient test got its rounding floor (cone_core.h, gfloor).
+  * p2      (round 4, tools/fuzz/fuzz_gpu.py seed 3001) the same situation on a 6 x 16 +-1 cone with a duplicated row: the
+            iteration stagnated at a projected gradient of 1e-12 (35 rounding floors) with f no longer decreasing, and
+            was flagged NOT_CONVERGED with the projection exact to 2e-16 -- the stagnation exits now accept 1e3 floors.
 Run from the repo root (needs /root/reference and scipy; NOT run on the GPU box):
     python tests/golden/make_regress.py
 """
@@ -53,6 +56,9 @@ def main():
     if "p1_A" not in cases:  # added in round 3 (the prediction enters with the sign the kernel saw: sign * pred = -y)
         z = np.load(os.path.join(ROOT, "tools", "diag", "noconv_r03.npz"))
         cases["p1_A"], cases["p1_y"] = z["A"], (-z["y"]).astype(np.float32)
+    if "p2_A" not in cases:  # added in round 4
+        z = np.load(os.path.join(ROOT, "tools", "diag", "noconv_r04.npz"))
+        cases["p2_A"], cases["p2_y"] = z["A"], (-z["y"]).astype(np.float32)
     out = dict(cases)
     for k in sorted(cases):
         if not k.endswith("_A"):
