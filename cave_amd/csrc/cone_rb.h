@@ -141,6 +141,48 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   // couple of LDS reads and a barrier; whether everybody is done is asked every eighth round.
   uint32_t open = 0;
   for (int u = 0; u < 32; ++u) open |= (tid + u * NT < p) ? (1u << u) : 0u;
+  constexpr int RPT = 8;  // rows per thread whose earlier neighbours are cached in registers (p <= RPT * NT)
+  if (p <= RPT * NT) {
+    // the earlier neighbours of this thread's rows, read once (0xffff: none): a round is then one batch of state reads
+    // (59 rounds on a 30 x 30 grid at ~3 k cycles each: ~90 us of a 3.5 ms instance -- with the checkerboard written
+    // directly, as a timing experiment, the kernel took 3.43 ms instead of 3.51; the rounds are instruction-bound)
+    uint16_t low[RPT][kRbDeg];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int i = tid + u * NT;
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) {
+        const uint32_t o = i < p ? (uint32_t)oth[i * kRbDeg + s] : 0xffffu;
+        low[u][s] = (uint16_t)((o < (uint32_t)i) ? o : 0xffffu);
+      }
+    }
+    for (int round = 0; round <= p + 8; ++round) {
+      uint8_t x[RPT][kRbDeg];
+      uint32_t live = 0;  // (wave-uniform) the row groups some lane of this wave still has open
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) live |= (__ballot((open >> u) & 1u) != 0ull) ? (1u << u) : 0u;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u)
+        if ((live >> u) & 1u) {
+#pragma unroll
+          for (int s = 0; s < kRbDeg; ++s) x[u][s] = (((open >> u) & 1u) && low[u][s] != 0xffffu) ? st[low[u][s]] : (uint8_t)2;
+        }
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        if (!((open >> u) & 1u)) continue;
+        bool wait = false, red_nb = false;
+#pragma unroll
+        for (int s = 0; s < kRbDeg; ++s) {
+          red_nb = red_nb || x[u][s] == 1;
+          wait = wait || x[u][s] == 0;
+        }
+        if (red_nb) { st[tid + u * NT] = 2; open &= ~(1u << u); }
+        else if (!wait) { st[tid + u * NT] = 1; open &= ~(1u << u); }
+      }
+      c.sync();
+      if ((round & 7) == 7 && c.reduce_add_u32(open != 0u ? 1u : 0u) == 0u) break;
+    }
+  } else
   for (int round = 0; round <= p + 8; ++round) {
     uint32_t m = open;
     while (m) {
@@ -210,43 +252,55 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   const auto rec = space_cast<1>(rb.rec);
   const auto badj = space_cast<1>(rb.badj);
   double span = 0.0;
-  for (int q = tid; q < nB; q += NT) {
-    const uint32_t b = lblk[q];
-    uint32_t at = lrp[q], a1[kRbDeg], a2[kRbDeg][kRbDeg];
+  constexpr int RF = 2;  // rows per thread in flight: their slots, then their red neighbours' slots (two memory levels)
+  for (int q0 = tid; q0 < nB; q0 += RF * NT) {
+    uint32_t bb[RF], a1[RF][kRbDeg], a2[RF][kRbDeg][kRbDeg];
 #pragma unroll
-    for (int s = 0; s < kRbDeg; ++s) a1[s] = adjG[b * kRbDeg + s];
+    for (int u = 0; u < RF; ++u) {
+      bb[u] = lblk[q0 + u * NT < nB ? q0 + u * NT : nB - 1];
 #pragma unroll
-    for (int s = 0; s < kRbDeg; ++s)
+      for (int s = 0; s < kRbDeg; ++s) a1[u][s] = adjG[bb[u] * kRbDeg + s];
+    }
 #pragma unroll
-      for (int s2 = 0; s2 < kRbDeg; ++s2) a2[s][s2] = adjG[(a1[s] == 0xffffffffu ? b : (a1[s] >> 16)) * kRbDeg + s2];
-    auto emit = [&](uint32_t k1, uint32_t k2, uint32_t r, uint32_t offs, uint32_t first) {
-      rec[2u * at] = k1 | (k2 << 16);
-      rec[2u * at + 1u] = r | ((offs & 0xffu) << 16) | (first << 24);
-      span = fmax(span, (double)offs);
-      ++at;
-    };
+    for (int u = 0; u < RF; ++u)
 #pragma unroll
-    for (int s = 0; s < kRbDeg; ++s) {
-      const uint32_t a = a1[s];
-      const uint32_t o1 = a >> 16;
-      uint32_t bslot = 0xffffffffu;  // (coordinate | sign, red neighbour) of the black row at position q
-      if (a != 0xffffffffu) {
-        if (st[o1] == 2) {
-          const int j = (int)lpos[o1];
-          if (j > q) emit(a & 0xffffu, 0xffffu, 0u, (uint32_t)(j - q), 0u);
-        } else {
-          bslot = a;
-          uint32_t first = 1u;
+      for (int s = 0; s < kRbDeg; ++s)
 #pragma unroll
-          for (int s2 = 0; s2 < kRbDeg; ++s2) {
-            const uint32_t b2 = a2[s][s2];
-            if (b2 == 0xffffffffu) continue;
-            const int j = (int)lpos[b2 >> 16];
-            if (j >= q) { emit(a & 0xffffu, b2 & 0xffffu, o1, (uint32_t)(j - q), first); first = 0u; }
+        for (int s2 = 0; s2 < kRbDeg; ++s2) a2[u][s][s2] = adjG[(a1[u][s] == 0xffffffffu ? bb[u] : (a1[u][s] >> 16)) * kRbDeg + s2];
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+      const int q = q0 + u * NT;
+      if (q >= nB) continue;
+      uint32_t at = lrp[q];
+      auto emit = [&](uint32_t k1, uint32_t k2, uint32_t r, uint32_t offs, uint32_t first) {
+        rec[2u * at] = k1 | (k2 << 16);
+        rec[2u * at + 1u] = r | ((offs & 0xffu) << 16) | (first << 24);
+        span = fmax(span, (double)offs);
+        ++at;
+      };
+#pragma unroll
+      for (int s = 0; s < kRbDeg; ++s) {
+        const uint32_t a = a1[u][s];
+        const uint32_t o1 = a >> 16;
+        uint32_t bslot = 0xffffffffu;  // (coordinate | sign, red neighbour) of the black row at position q
+        if (a != 0xffffffffu) {
+          if (st[o1] == 2) {
+            const int j = (int)lpos[o1];
+            if (j > q) emit(a & 0xffffu, 0xffffu, 0u, (uint32_t)(j - q), 0u);
+          } else {
+            bslot = a;
+            uint32_t first = 1u;
+#pragma unroll
+            for (int s2 = 0; s2 < kRbDeg; ++s2) {
+              const uint32_t b2 = a2[u][s][s2];
+              if (b2 == 0xffffffffu) continue;
+              const int j = (int)lpos[b2 >> 16];
+              if (j >= q) { emit(a & 0xffffu, b2 & 0xffffu, o1, (uint32_t)(j - q), first); first = 0u; }
+            }
           }
         }
+        badj[q * kRbDeg + s] = bslot;
       }
-      badj[q * kRbDeg + s] = bslot;
     }
   }
   // red rows: (coordinate | sign, position of the black neighbour) per slot
