@@ -719,7 +719,7 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
                                                   const double* rhs_v, const uint8_t* act_v, const int p_v,
                                                   const double reg_rel, double* win_v, double* fac_v, double* z_v,
                                                   double* x_v, const BandGen* gen_v = nullptr,
-                                                  unsigned long long* stamps = nullptr) {
+                                                  unsigned long long* stamps = nullptr, const int x_cap_v = -1) {
   constexpr int U = kBandWaveDuos, RMAX = kBandWaveRegs, NB = kBandBlock, G = kBandGroup;
   constexpr bool DUO = NW >= 2;  // a producer wave exists
   const int wave = __builtin_amdgcn_readfirstlane(wave_v);
@@ -762,7 +762,10 @@ CAVE_NOINLINE __device__ void solve_spd_band_wave(const int lane, const int wave
   // Component-major: the lanes of a duo round read consecutive t, i.e. consecutive words (as [t][a] records the
   // same reads were 16-way bank conflicts: rocprof counted 1.0e9 conflict cycles per launch on the 30x30 batch)
   const int ncol = bw + NB + 2;
-  auto scrP = ((uint32_t)p >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 3);
+  // (x_cap: entries x really has -- the red-black form solves nB < p rows in the arrays of a p-row system, whose LDS
+  // region was sized for p: the scratch stays where that sizing put it)
+  const int x_cap = __builtin_amdgcn_readfirstlane(x_cap_v) >= 0 ? __builtin_amdgcn_readfirstlane(x_cap_v) : p;
+  auto scrP = ((uint32_t)x_cap >= band_wave_scratch(bw)) ? x : win + (band_wave_flags_at(bw) + 3);
   auto scrQ = scrP + NB * ncol;
   double md = 0.0;
   uint32_t nfix = 0;

@@ -210,9 +210,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   const int nB = (int)c.compact_mask_u8(reinterpret_cast<const uint8_t*>(lbase), p, 0xff, 2, reinterpret_cast<uint32_t*>(lbase + rp_at));
   c.sync();
   rb.nB = nB;
-  if (nB >= p || nB < 1 || !band_wave_fits(bw, nB) ||
-      ((uint32_t)p >= band_wave_scratch(bw)) != ((uint32_t)nB >= band_wave_scratch(bw)))
-    return;
+  if (nB >= p || nB < 1 || !band_wave_fits(bw, nB)) return;
   for (int i = tid; i < p; i += NT) cls[i] = st[i];
   for (int q = tid; q < nB; q += NT) {
     const uint32_t b = lrp[q];
@@ -440,11 +438,13 @@ CAVE_HD void rb_solve(C& c, const SolveView& v, SolveWork& w, const double* rhs,
   // the band solver on the black rows: its producer builds the rows of S from the recipes (cone_band.h band_gen_rows_rb)
   BandGen gen = w.gen;
   gen.rb = &w.rb;
-  solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), nullptr, bw, rb.gB, w.act, nB, 0.0, w.bwin, w.bfac, w.bz, w.step, &gen
+  solve_spd_band_wave<C::NWAVES>(c.lane_id(), c.wave_id(), nullptr, bw, rb.gB, w.act, nB, 0.0, w.bwin, w.bfac, w.bz, w.step, &gen,
 #ifdef CAVE_STAMPS
-                                 , c.st
+                                 c.st,
+#else
+                                 nullptr,
 #endif
-  );
+                                 p);  // (x and the LDS region were sized for p rows)
   c.sync();
   // back to the order of the reduced rows: black rows copy, red rows follow in closed form
   for (int q = tid; q < nB; q += NT) w.bz[q] = w.step[q];

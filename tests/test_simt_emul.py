@@ -113,17 +113,19 @@ def test_band_elimination_under_emulation(emul, simt, golden, waves):
     assert simt.path_counters()[1] == 4  # the one-wave band form ran for every instance
 
 
-def test_red_black_reduction_of_the_band_under_emulation(emul, simt):
-    """cone_rb.h: a 24 x 24 grid (576 free rows, half bandwidth 24; 288 of them stay in the band system) on the two-wave
-    shape -- the adjacency, the greedy independent set, the recipes, the producer building rows of the Schur complement,
-    the closed-form red rows -- against the serial build of the same source (which has no one-wave band form and
-    therefore factors the full band), round-robin and shuffled schedules."""
+@pytest.mark.parametrize("side", [24, 20])
+def test_red_black_reduction_of_the_band_under_emulation(emul, simt, side):
+    """cone_rb.h: grids of 24 x 24 (576 free rows, half bandwidth 24; 288 of them stay in the band system) and 20 x 20 (the
+    black half, 200 rows, is smaller than the operand scratch the solver was sized for: 208) on the two-wave shape -- the
+    adjacency, the greedy independent set, the recipes, the producer building rows of the Schur complement, the closed-form
+    red rows -- against the serial build of the same source (which has no one-wave band form and therefore factors the
+    full band), round-robin and shuffled schedules."""
     from cave_amd import synth
 
-    c, y, _ = synth.sp_batch(24, 24, 1, seed=5)
+    c, y, _ = synth.sp_batch(side, side, 1, seed=5)
     st, arrs, mr, _ = emul.pack_large(c)
     bw = store_bandwidth(arrs, 1, c.shape[2])
-    assert (mr, bw) == (576, 24)
+    assert (mr, bw) == (side * side, side)
     ref = emul.cone_packed_large(st, arrs, mr, np.arange(1), y, MODE_PROJECT, sign=-1.0)
     assert (ref["status"] == 0).all()
     # what ConeStore._fold_signs does when it finalises a store of this path: the signs of an all-+-1 instance go into
