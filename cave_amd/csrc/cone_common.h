@@ -152,6 +152,8 @@ enum : int32_t {
                        // interior-point solver: src/cave.py:213-214,267-295; emulation, parity unpinned)
 };
 
+static constexpr uint32_t kTeamRow = 1024;  // entries: longer rows are summed by all waves of the workgroup together
+
 // reference thresholds
 static constexpr float kDropRowAbsSum = 1e-7f;  // src/cave.py:303
 static constexpr float kAvgRowNorm = 1e-7f;     // src/cave.py:225
@@ -220,6 +222,8 @@ struct SolveView {
   const uint8_t* usign;   // [d]  bit0: +e_k row present, bit1: -e_k row present
   int nlong;              // reduced rows with more than kLongRow entries ...
   const uint32_t* longrow;  // ... and their indices
+  int nteam = 0;            // of those, rows with more than kTeamRow entries (shared by the waves in the streamed gradient) ...
+  const uint32_t* teamrow = nullptr;  // ... and their indices
   bool csc_far = false;   // "diet" layout (TSP-50 class: cone_instance.h run_packed_instance): cvar points into the packed
                           // store (global memory, signs in bit 15), read with batched loads; cptr stays in LDS
 };

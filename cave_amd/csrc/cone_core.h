@@ -977,12 +977,17 @@ CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double*
   const int lane = c.lane_id();
   const auto mptr = space_cast<1>(v.mptr);
   const uint32_t last = mptr[v.p] > 0u ? mptr[v.p] - 1u : 0u;
+  // Rows of more than kTeamRow entries (the large subtour cuts of a TSP-100 cone: up to 4 700) are SHARED by the waves,
+  // below: one wave per row left the wave that drew two of them with 50 steps where the others had 31 -- the gradient
+  // of the slowest instances, i.e. of the kernel.
+  constexpr uint32_t kTeam = (NW > 1) ? kTeamRow : 0xffffffffu;
   for (int l0 = c.wave_id(); l0 < v.nlong; l0 += 2 * NW) {
     const int l1 = l0 + NW;
     const bool two = l1 < v.nlong;
     const int i0 = (int)v.longrow[l0], i1 = two ? (int)v.longrow[l1] : i0;
-    const uint32_t lo0 = mptr[i0], n0 = mptr[i0 + 1] - lo0;
-    const uint32_t lo1 = mptr[i1], n1 = two ? mptr[i1 + 1] - lo1 : 0u;
+    const uint32_t lo0 = mptr[i0], m0 = mptr[i0 + 1] - lo0;
+    const uint32_t lo1 = mptr[i1], m1 = two ? mptr[i1 + 1] - lo1 : 0u;
+    const uint32_t n0 = m0 > kTeam ? 0u : m0, n1 = m1 > kTeam ? 0u : m1;
     double part0 = 0.0, part1 = 0.0;
     for (uint32_t off = 0; off < n0 || off < n1; off += (uint32_t)(U * WL)) {
       uint32_t col[2][U];
@@ -1006,8 +1011,33 @@ CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double*
     part0 = c.wave_sum(part0);
     part1 = c.wave_sum(part1);
     if (lane == 0) {
-      g[i0] = part0;
-      if (two) g[i1] = part1;
+      if (m0 <= kTeam) g[i0] = part0;
+      if (two && m1 <= kTeam) g[i1] = part1;
+    }
+  }
+  if constexpr (NW > 1) {
+    for (int l = 0; l < v.nteam; ++l) {  // (workgroup-uniform: every wave walks the short list of such rows)
+      const int i = (int)v.teamrow[l];
+      const uint32_t lo = mptr[i], n = mptr[i + 1] - lo;
+      double part = 0.0;
+      for (uint32_t off = (uint32_t)(c.wave_id() * U * WL); off < n; off += (uint32_t)(NW * U * WL)) {
+        uint32_t col[U];
+        double val[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t t = off + (uint32_t)(u * WL + lane);
+          csr_entry<PM1, 1>(v, lo + t < last ? lo + t : last, col[u], val[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = rc[col[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t t = off + (uint32_t)(u * WL + lane);
+          part -= t < n ? val[u] * x[u] : 0.0;
+        }
+      }
+      part = c.reduce_sum(part);  // lanes, then waves, in a fixed order
+      if (c.tid() == 0) g[i] = part;
     }
   }
 }

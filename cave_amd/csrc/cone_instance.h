@@ -392,6 +392,15 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
     vv.longrow = llist;
     c.sync();
+    if constexpr (LARGE) {  // (the streamed gradient shares very long rows between the waves)
+      uint32_t* tlist = ar.get<uint32_t>(pp);
+      if (ar.ovf) return ST_TOO_LARGE;
+      for (int i = c.tid(); i < p; i += C::NT) lflag[i] = (uint8_t)((v.mptr[i + 1] - v.mptr[i]) > kTeamRow ? 1 : 0);
+      c.sync();
+      vv.nteam = (int)c.compact_nonzero_u8(lflag, p, tlist);
+      vv.teamrow = tlist;
+      c.sync();
+    }
     SolveResult r;
     bool lite = false;
     if constexpr (LARGE) {
@@ -848,7 +857,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
                    align8u(rows_raw) + align8u(2 * m) +
                    (2 * align8u(8 * rows_raw) > align8u(4 * d) ? 2 * align8u(8 * rows_raw) : align8u(4 * d)) + align8u(4 * p);
   uint64_t vecs = 2 * align8u(4 * d);
-  uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 8 * align8u(8 * p) + 2 * align8u(p) + align8u(4 * p) +
+  uint64_t solve = 3 * align8u(8 * d) + align8u(d) + 8 * align8u(8 * p) + 2 * align8u(p) + 2 * align8u(4 * p) +
                    3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096;  // H, factor, ring window ((bw+1)^2 <= p*(bw+1)), staging
   uint64_t build_peak = persist + scan + temps + vecs;
   uint64_t solve_peak = persist + vecs + solve;
@@ -857,7 +866,7 @@ static inline uint64_t large_slice_bytes(int64_t m, int64_t d, int64_t cap, int6
 static inline uint64_t packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t band) {
   const int64_t p = max_rows > 0 ? max_rows : 1;
   return align8u(4 * d) + align8u(4 * (p + 1)) + 3 * align8u(8 * d) + align8u(d) + 8 * align8u(8 * p) + 2 * align8u(p) +
-         align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096 + 256;  // + staging buffers (at most 4096 entries each)
+         2 * align8u(4 * p) + 3 * (uint64_t)8 * (uint64_t)(band + 1) + 2 * 8 * 4096 + 256;  // + staging buffers (at most 4096 entries each)
 }
 
 // LDS for the hot arrays of the large-cone path (solve_and_finish<LARGE> allocates in this order: window, z, step,
