@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "cave_hip_cone_dense", "cave_hip_pack_count", "cave_hip_pack_fill", "cave_hip_cone_packed",
     "cave_hip_packed_lds_bytes",
     "cave_hip_large_slice_bytes", "cave_hip_packed_large_slice_bytes", "cave_hip_cone_dense_large",
-    "cave_hip_pack_large", "cave_hip_cone_packed_large", "cave_hip_packed_large_lds_bytes",
+    "cave_hip_pack_large", "cave_hip_cone_packed_large", "cave_hip_packed_large_lds_bytes", "cave_hip_packed_large_rb_bytes",
     "cave_hip_step_lds_bytes", "cave_hip_cone_step", "cave_hip_lite_from_packed",
 )
 
@@ -89,6 +89,7 @@ class Store(C.Structure):
         ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),
         ("n_rows", C.c_void_p), ("n_nnz", C.c_void_p),  # slot mode only (NULL in an exact-fit store)
         ("warm_theta", C.c_void_p), ("warm_state", C.c_void_p),  # warm start (NULL: off)
+        ("rb_cache", C.c_void_p), ("rb_stride", C.c_int64),  # red-black cache of the large path (NULL: off)
     ]
 
 
@@ -139,6 +140,8 @@ def load_library() -> C.CDLL:
     lib.cave_hip_packed_large_slice_bytes.restype = i64
     lib.cave_hip_packed_large_lds_bytes.argtypes = [i32, i32]
     lib.cave_hip_packed_large_lds_bytes.restype = i32
+    lib.cave_hip_packed_large_rb_bytes.argtypes = [i64]
+    lib.cave_hip_packed_large_rb_bytes.restype = i64
     lib.cave_hip_cone_dense_large.argtypes = [vp, vp, i64, i64, i64, i32, f32, f32, i32, i64, i32, vp, i64, i32,
                                               vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cave_hip_pack_large.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, vp, vp, C.POINTER(Store), i64, vp, vp]

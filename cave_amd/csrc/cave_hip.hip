@@ -185,6 +185,8 @@ int32_t cave_hip_packed_large_lds_bytes(int32_t max_rows, int32_t max_bw) {
   return (int32_t)packed_large_lds_bytes(max_rows, max_bw);
 }
 
+int64_t cave_hip_packed_large_rb_bytes(int64_t max_rows) { return (int64_t)rb_cache_bytes(max_rows); }
+
 static int32_t check_large(const char* who, const void* workspace, int64_t slice_bytes, int32_t n_slots, int32_t& lds_bytes) {
   if (!workspace || slice_bytes < 1024 || slice_bytes >= ((int64_t)1 << 32) || (slice_bytes & 7) || n_slots <= 0 ||
       ((uintptr_t)workspace & 15u)) {

@@ -153,7 +153,7 @@ template <class C, bool LARGE = false>
 CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v, int mode, float sign,
                                  float inner_ratio, int max_iter, float* y, const float* avg, int64_t b,
                                  const OutPtrs& o, int* iters_out, float* warm_theta = nullptr,
-                                 uint8_t* warm_state = nullptr) {
+                                 uint8_t* warm_state = nullptr, unsigned char* rb_cache = nullptr, uint64_t rb_cache_bytes = 0) {
   const int d = v.d;
   const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER || mode == MODE_IPM);
   CAVE_T0();  // (stamp builds, large path: slot 0 = set-up before the solver, 1 = the solver call, 9 = epilogue)
@@ -333,7 +333,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
       } else w.H = nullptr;
 #if defined(CAVE_GPU_CODE) && !defined(CAVE_NO_RB)  // (diagnostic builds can pin the full-size band)
       if (rb_wanted && mode != MODE_IPM) {
-        rb_setup(c, v, w);
+        rb_setup(c, v, w, rb_cache, rb_cache_bytes);
 #ifdef CAVE_EMUL_COUNTERS
         if (c.tid() == 0 && w.rb.on) ++emul_counters()[5];
 #endif
@@ -777,7 +777,9 @@ CAVE_HD void run_packed_large_instance(C& c, unsigned char* smem, const PackedPa
       const float* avg = need_avg ? S.avg + slot * d : nullptr;
       st = solve_and_finish<C, true>(c, ar, &hot, v, P.mode, P.sign, P.inner_ratio, P.max_iter, y, avg, b, P.o, &iters,
                                      S.warm_theta ? S.warm_theta + r0 : nullptr,
-                                     S.warm_state ? S.warm_state + slot : nullptr);
+                                     S.warm_state ? S.warm_state + slot : nullptr,
+                                     S.rb_cache ? S.rb_cache + slot * S.rb_stride : nullptr,
+                                     S.rb_cache ? (uint64_t)S.rb_stride : 0ull);
     }
   }
   if (st == ST_TOO_LARGE || st == ST_BAD_INPUT) fill_failure(c, d, b, P.o);

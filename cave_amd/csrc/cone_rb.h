@@ -25,18 +25,76 @@
 namespace cave {
 
 constexpr int kRbDeg = 4;  // neighbour slots per row
+constexpr uint32_t kRbRecPerRow = 12;  // records the persistent cache holds per reduced row (a grid needs ~5)
+
+// Bytes of the per-instance cache (cave_cone_store.rb_cache) for cones of up to `p` reduced rows: what the reduction
+// derives from the STATIC cone alone -- header (state, black rows, records), black rows, recipe pointers, the red and
+// the black neighbour slots, positions, classes, the records -- so that only an instance's first projection builds it.
+CAVE_HOSTDEV uint64_t rb_cache_bytes(int64_t p) {
+  if (p < 8 || p > 0x7fff) return 0;
+  const uint64_t P = (uint64_t)p;
+  auto a16 = [](uint64_t x) { return (x + 15ull) & ~15ull; };
+  return 64ull + a16(4 * P) + a16(4 * (P + 1)) + 2 * a16(4ull * kRbDeg * P) + a16(2 * P) + a16(P) + a16(8ull * kRbRecPerRow * P);
+}
 
 #if defined(CAVE_GPU_CODE)
 // adjacency slot: coordinate (bit 15: sign of the product of the two entries of its column) | neighbour << 16;
 // 0xffffffff = empty
+// `cache` / `cache_bytes`: this instance's block of the store's persistent cache (rb_cache_bytes), or null: header word 0
+// = 0 nothing yet, 1 built (word 1: black rows), 2 this cone does not take the reduction.
 template <class C>
-CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
+CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w, unsigned char* cache = nullptr, uint64_t cache_bytes = 0) {
   constexpr int NT = C::NT;
   const int p = v.p, d = v.d, ldh = w.ldh, bw = w.bw, tid = c.tid();
   RbWork& rb = w.rb;
   rb.on = false;
-  if (!v.pm1 || p < 8 || p > 0x7fff || d > 0x7fff) return;
-  if (p > 32 * NT) return;  // (a thread keeps its undecided rows in one word below)
+  if (cache && cache_bytes < rb_cache_bytes(p)) cache = nullptr;
+  // ---- carve: per-call arrays in the workspace block of the (never materialised) band, the persistent ones in the cache
+  // when there is one (else behind them)
+  unsigned char* base = reinterpret_cast<unsigned char*>(w.H);
+  const uint64_t room = 8ull * (uint64_t)p * (uint64_t)ldh;
+  uint64_t off = 0;
+  auto take = [&](uint64_t bytes) { unsigned char* q = base + off; off += (bytes + 15ull) & ~15ull; return q; };
+  rb.wt = reinterpret_cast<double*>(take(8ull * d));
+  rb.hd = reinterpret_cast<double*>(take(8ull * p));
+  rb.hdB = reinterpret_cast<double*>(take(8ull * p));
+  rb.gB = reinterpret_cast<double*>(take(8ull * p));
+  uint32_t* adjG_ = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));  // adjacency slots (set-up only)
+  unsigned char* pbase = base;
+  uint64_t poff = off, proom = room;
+  if (cache) { pbase = cache; poff = 64; proom = cache_bytes; }
+  auto ptake = [&](uint64_t bytes) { unsigned char* q = pbase + poff; poff += (bytes + 15ull) & ~15ull; return q; };
+  rb.blk = reinterpret_cast<uint32_t*>(ptake(4ull * p));
+  rb.rp = reinterpret_cast<uint32_t*>(ptake(4ull * (p + 1)));
+  rb.radj = reinterpret_cast<uint32_t*>(ptake(4ull * kRbDeg * p));
+  rb.badj = reinterpret_cast<uint32_t*>(ptake(4ull * kRbDeg * p));
+  rb.pos = reinterpret_cast<uint16_t*>(ptake(2ull * p));
+  rb.cls = reinterpret_cast<uint8_t*>(ptake(1ull * p));
+  rb.rec = reinterpret_cast<uint32_t*>(ptake(0));
+  if (off >= room || poff >= proom) return;
+  volatile uint32_t* hdr = reinterpret_cast<volatile uint32_t*>(cache);
+  if (cache) {
+    // one thread reads the state, the workgroup agrees on it (another workgroup solving the same instance may be
+    // writing it right now: whoever sees "built" finds complete data behind the fence, the others build the same)
+    uint32_t stt = 0, nb = 0;
+    if (tid == 0) { stt = hdr[0]; nb = hdr[1]; }
+    stt = c.reduce_add_u32(stt);
+    nb = c.reduce_add_u32(nb);
+    if (stt == 2u) return;
+    if (stt == 1u) {
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+      __threadfence();
+#endif
+      rb.nB = (int)nb;
+      rb.on = true;
+      return;
+    }
+  }
+  auto give_up = [&]() {  // remember that this cone does not take the reduction
+    if (cache && tid == 0) hdr[0] = 2u;
+  };
+  if (!v.pm1 || p < 8 || p > 0x7fff || d > 0x7fff) return give_up();
+  if (p > 32 * NT) return give_up();  // (a thread keeps its undecided rows in one word below)
   const auto mptr = space_cast<1>(v.mptr);
   const auto mcol = space_cast<1>(v.mcol);
   const auto cptr = space_cast<1>(v.cptr);
@@ -48,24 +106,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
                          [&](int, const LdE& x) { bad += (x.hi - x.lo > 2u) ? 1u : 0u; });
   strided_batched<8, NT>(tid, p, [&](int i) { return LdE{mptr[i], mptr[i + 1]}; },
                          [&](int, const LdE& x) { bad += (x.hi - x.lo > (uint32_t)kRbDeg) ? 1u : 0u; });
-  if (c.reduce_add_u32(bad) != 0u) return;
-  // ---- carve the workspace block of the (never materialised) band
-  unsigned char* base = reinterpret_cast<unsigned char*>(w.H);
-  const uint64_t room = 8ull * (uint64_t)p * (uint64_t)ldh;
-  uint64_t off = 0;
-  auto take = [&](uint64_t bytes) { unsigned char* q = base + off; off += (bytes + 15ull) & ~15ull; return q; };
-  rb.wt = reinterpret_cast<double*>(take(8ull * d));
-  rb.hd = reinterpret_cast<double*>(take(8ull * p));
-  rb.hdB = reinterpret_cast<double*>(take(8ull * p));
-  rb.gB = reinterpret_cast<double*>(take(8ull * p));
-  rb.blk = reinterpret_cast<uint32_t*>(take(4ull * p));
-  rb.rp = reinterpret_cast<uint32_t*>(take(4ull * (p + 1)));
-  rb.radj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
-  rb.badj = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));
-  uint32_t* adjG_ = reinterpret_cast<uint32_t*>(take(4ull * kRbDeg * p));  // adjacency slots (set-up only)
-  rb.pos = reinterpret_cast<uint16_t*>(take(2ull * p));
-  rb.cls = reinterpret_cast<uint8_t*>(take(1ull * p));
-  rb.rec = reinterpret_cast<uint32_t*>(take(0));
+  if (c.reduce_add_u32(bad) != 0u) return give_up();
   // LDS (the idle ring of the band solver) holds what the set-up walks again and again: states [p] bytes, positions and
   // black rows [p] halfwords each, the neighbours [p][kRbDeg] halfwords, row pointers of the recipes [p + 1] words (first
   // the compacted list of black rows).  17 p bytes; the workspace receives the results and the full adjacency slots.
@@ -74,7 +115,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   const uint32_t blk_at = (pos_at + 2u * (uint32_t)p + 15u) & ~15u;
   const uint32_t oth_at = (blk_at + 2u * (uint32_t)p + 15u) & ~15u;
   const uint32_t rp_at = (oth_at + 2u * kRbDeg * (uint32_t)p + 15u) & ~15u;
-  if (off >= room || (uint64_t)rp_at + 4ull * (p + 1) > lds_room) return;
+  if ((uint64_t)rp_at + 4ull * (p + 1) > lds_room) return;
   unsigned char* lbase = reinterpret_cast<unsigned char*>(w.bwin);
   auto st = space_cast<3>(reinterpret_cast<uint8_t*>(lbase));
   auto lpos = space_cast<3>(reinterpret_cast<uint16_t*>(lbase + pos_at));
@@ -210,7 +251,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   const int nB = (int)c.compact_mask_u8(reinterpret_cast<const uint8_t*>(lbase), p, 0xff, 2, reinterpret_cast<uint32_t*>(lbase + rp_at));
   c.sync();
   rb.nB = nB;
-  if (nB >= p || nB < 1 || !band_wave_fits(bw, nB)) return;
+  if (nB >= p || nB < 1 || !band_wave_fits(bw, nB)) return give_up();
   for (int i = tid; i < p; i += NT) cls[i] = st[i];
   for (int q = tid; q < nB; q += NT) {
     const uint32_t b = lrp[q];
@@ -245,7 +286,7 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
   if (tid == 0) lrp[nB] = 0u;
   c.sync();
   const uint32_t nrec = c.exclusive_scan_u32(reinterpret_cast<uint32_t*>(lbase + rp_at), nB + 1);
-  if (off + 8ull * (uint64_t)nrec > room) return;
+  if (poff + 8ull * (uint64_t)nrec > proom) return give_up();
   for (int q = tid; q <= nB; q += NT) rp[q] = lrp[q];
   const auto rec = space_cast<1>(rb.rec);
   const auto badj = space_cast<1>(rb.badj);
@@ -313,8 +354,21 @@ CAVE_HD void rb_setup(C& c, const SolveView& v, SolveWork& w) {
                          });
   const int bwS = (int)c.reduce_max(span);
   c.sync();
-  if (bwS > bw || bwS > 255) return;
+  if (bwS > bw || bwS > 255) return give_up();
   rb.on = true;
+  if (cache) {  // publish: the data first, then the state
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+    __threadfence();
+#endif
+    c.sync();
+    if (tid == 0) {
+      hdr[1] = (uint32_t)nB;
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL)
+      __threadfence();
+#endif
+      hdr[0] = 1u;
+    }
+  }
 }
 
 // One Newton system: (H + shift I) step = rhs, H = M W M^T with this iteration's weights (w.gen.r, w.gen.mu).

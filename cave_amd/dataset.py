@@ -27,6 +27,8 @@ __all__ = ["ConeStore", "PackedBatch", "collate_ids", "prefetch"]
 
 
 class ConeStore:
+    RB_CACHE_MAX_BYTES = 4 << 30  # cap of the large path's red-black cache (see _finalize; 128 MB for 1024 30x30 grids)
+
     def __init__(self, d: int, device: torch.device):
         self.d = int(d)
         self.device = device
@@ -214,6 +216,15 @@ class ConeStore:
         self.large_lds = int(lib.cave_hip_packed_large_lds_bytes(int(self.max_rows), int(self.max_bw))) if self.large else 0
         if self.large or self.lds_bytes_diet:
             self._fold_signs()
+        self.rb_cache = None
+        if self.large and self.all_pm1 and self.n > 0:
+            # band systems of cones without bound rows (grid shortest path): what the red-black reduction derives from the
+            # static cone -- independent set, recipes of the Schur complement -- is kept per instance after its first
+            # projection (include/cave_hip.h rb_cache; ~140 bytes per reduced row).  Skipped beyond RB_CACHE_MAX_BYTES.
+            stride = int(lib.cave_hip_packed_large_rb_bytes(int(self.max_rows)))
+            if 0 < stride and self.n * stride <= self.RB_CACHE_MAX_BYTES:
+                self.rb_cache = torch.zeros(self.n * stride, dtype=torch.uint8, device=dev)
+                self._c.rb_cache, self._c.rb_stride = self.rb_cache.data_ptr(), stride
         self._build_lite()
         return self
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CAVE_HIP_ABI_VERSION 9
+#define CAVE_HIP_ABI_VERSION 10
 
 /* return codes */
 #define CAVE_OK 0
@@ -166,6 +166,13 @@ typedef struct cave_cone_store {
    * projection is unique, so results are the same as from a cold start (to the solver's tolerance). */
   float* warm_theta;
   uint8_t* warm_state;
+  /* Red-black cache (v10; NULL: off).  rb_cache [n * rb_stride] bytes, ZEROED by the caller, rb_stride from
+   * cave_hip_packed_large_rb_bytes(max_rows).  cave_hip_cone_packed_large keeps there, per instance, what its red-black
+   * reduction of the band systems (grid shortest-path cones) derives from the STATIC cone alone -- the independent set
+   * of reduced rows, the recipes of the Schur complement -- so that only the first projection of an instance builds
+   * it (cones are static per instance, src/dataset.py:72).  Results do not depend on it. */
+  uint8_t* rb_cache;
+  int64_t rb_stride;
 } cave_cone_store;
 
 /* Pass 2: fill the store for instances [0, B) of `ctrs` at store slots [slot0, slot0+B). */
@@ -212,6 +219,9 @@ int64_t cave_hip_packed_large_slice_bytes(int64_t d, int64_t max_rows, int64_t b
  * (max_bw <= 34) are eliminated by ONE wave per instance; the figure returned for them is the exact need, so that
  * four workgroups share a CU (the 2- and 1-wave forms of cave_hip_cone_packed_large are chosen from it). */
 int32_t cave_hip_packed_large_lds_bytes(int32_t max_rows, int32_t max_bw);
+/* Bytes per instance of cave_cone_store.rb_cache for reduced systems of up to max_rows rows (v10); 0: such cones never
+ * take the red-black reduction. */
+int64_t cave_hip_packed_large_rb_bytes(int64_t max_rows);
 
 int32_t cave_hip_cone_dense_large(const float* ctrs, const float* pred, int64_t B, int64_t m_max, int64_t d,
                                   int32_t mode, float sign, float inner_ratio, int32_t max_iter, int64_t nnz_cap,

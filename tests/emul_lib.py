@@ -49,6 +49,7 @@ class Store(C.Structure):
         ("cptr", C.c_void_p), ("cvar", C.c_void_p), ("cvalc", C.c_void_p),
         ("n_rows", C.c_void_p), ("n_nnz", C.c_void_p),  # slot mode only (NULL in an exact-fit store)
         ("warm_theta", C.c_void_p), ("warm_state", C.c_void_p),  # warm start (NULL: off)
+        ("rb_cache", C.c_void_p), ("rb_stride", C.c_int64),  # red-black cache of the large path (NULL: off)
     ]
 
 

@@ -20,9 +20,21 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cave_hip_version() == 9
+    assert lib.cave_hip_version() == 10
     assert lib.cave_hip_device_count() >= 0
     assert int(re.search(r"#define CAVE_HIP_ABI_VERSION (\d+)", hdr).group(1)) == lib.cave_hip_version()
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check (__graft_entry__.build): every library is up to date here, so this only walks
+    the build steps and their assertions -- one of which compared the ABI version with a literal that two ABI bumps had
+    left behind (found in round 4)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+
+    __graft_entry__.build()
 
 
 def test_default_limits_and_arg_validation():

@@ -244,3 +244,36 @@ def test_training_example_prefetch_mode_matches_plain_loop():
     for (e0, l0, r0), (e1, l1, r1) in zip(plain[1:], pre[1:]):
         assert abs(l0 - l1) <= 2e-5 * max(1.0, abs(l0)), (e0, l0, l1)
         assert abs(r0 - r1) <= 1e-3, (e0, r0, r1)
+
+
+def test_red_black_cache_of_the_packed_store():
+    """ABI v10 rb_cache: grid shortest-path cones on the large path keep, per instance, what the red-black reduction of
+    their band systems derives from the static cone (cone_rb.h).  The first projection builds it, later ones reuse it:
+    same bits either way and without a cache; repeated ids in one batch (two workgroups building the same entry) too;
+    projections carry KKT certificates."""
+    import torch
+
+    from certificate import assert_projection
+    from cave_amd import synth
+    from cave_amd.dataset import ConeStore
+
+    c, y, _ = synth.sp_batch(24, 24, 6, seed=21)
+    rng = np.random.default_rng(3)
+    pred = (y + rng.normal(0, 0.05, y.shape)).astype(np.float32)
+    store = ConeStore.from_dense(torch.tensor(c, device="cuda"), chunk=3)
+    assert store.large and store.rb_cache is not None and int(store.rb_cache.max()) == 0
+    ids = torch.tensor([0, 1, 2, 3, 4, 5, 2, 2, 0], device="cuda")
+    p = torch.tensor(pred[ids.cpu().numpy()], device="cuda")
+    first = store.cone_op(ids, p, MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    stride = store._c.rb_stride
+    states = store.rb_cache.view(-1, stride)[:, :4].contiguous().view(torch.int32).flatten().tolist()
+    assert states == [1] * 6   # every instance built its entry (state word: 1 = built)
+    again = store.cone_op(ids, p, MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    plain = ConeStore.from_dense(torch.tensor(c, device="cuda"), chunk=3)
+    plain._c.rb_cache, plain._c.rb_stride, plain.rb_cache = None, 0, None
+    ref = plain.cone_op(ids, p, MODE_PROJECT, -1.0, 0.0, outputs=("proj", "rnorm"))
+    for k in ("proj", "rnorm", "iters"):
+        assert torch.equal(first[k], again[k]) and torch.equal(first[k], ref[k]), k
+    proj = first["proj"].cpu().numpy()
+    for j, i in enumerate(ids.tolist()):
+        assert_projection(c[i], -pred[i], proj[j], what=f"24x24 grid, instance {i}")
