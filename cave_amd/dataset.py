@@ -318,7 +318,8 @@ class ConeStore:
             self.t["warm_state"].zero_()
 
     def nbytes(self) -> int:
-        return sum(v.numel() * v.element_size() for v in self.t.values())
+        rb = getattr(self, "rb_cache", None)
+        return sum(v.numel() * v.element_size() for v in self.t.values()) + (rb.numel() if rb is not None else 0)
 
     def algorithmic_bytes(self, ids: torch.Tensor) -> int:
         """Bytes one projection pass must touch for these instances: packed rows + y in, proj/rnorm out
