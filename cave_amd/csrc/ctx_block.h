@@ -225,14 +225,20 @@ struct BlockCtx {
   // wave 0 solves in registers; the caller's sync() publishes dv to the other waves
   __device__ __forceinline__ void solve_spd(const double* H, int ldh, const double* g, const uint8_t* act, int p,
                                             double reg_rel, double* dv) const {
-    if (wave == 0) gj_solve_small<PMAX>(lane, H, ldh, g, act, p, reg_rel, dv);
+    if (wave == 0) {
+      if constexpr (WIDE && NW == 4) gj_solve_wide_call<false>(lane, H, ldh, g, act, p, reg_rel, dv);
+      else gj_solve_small<PMAX>(lane, H, ldh, g, act, p, reg_rel, dv);
+    }
   }
   // H as the packed lower triangle (diet layout).  (Tried, round 4: the two workgroups that share a compute unit in
   // that tier solving on DIFFERENT SIMDs -- wave 0 or wave 2 by the parity of the hardware wave slot: TSP-50, B = 512
   // 0.354 ms against 0.336 ms with both on their wave 0.  Dropped.)
   __device__ __forceinline__ void solve_spd_tri(const double* H, const double* g, const uint8_t* act, int p, double reg_rel,
                                                 double* dv) const {
-    if (wave == 0) gj_solve_small<PMAX, true>(lane, H, 0, g, act, p, reg_rel, dv);
+    if (wave == 0) {
+      if constexpr (WIDE && NW == 4) gj_solve_wide_call<true>(lane, H, 0, g, act, p, reg_rel, dv);
+      else gj_solve_small<PMAX, true>(lane, H, 0, g, act, p, reg_rel, dv);
+    }
   }
 
   // Cooperative ordered streaming scan (contract: see WaveCtx::scan_dense).  Per round, wave w owns

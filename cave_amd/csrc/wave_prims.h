@@ -126,12 +126,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   * nothing is selected between the pivot and its reciprocal: a non-positive / NaN pivot (numerically
 //     dependent row) is clamped for the reciprocal and masked out of the multiplier: the row is skipped, x_k = 0.
 // LOWER: only the lower triangle of H is valid (H[i][j], j <= i); the upper part is read transposed.
-template <int PM, bool LOWER = false, int G = 4>
-__device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh, const double* rhs,
-                                              const uint8_t* act, int p, double reg_rel, double* dv) {
+template <int PM, bool LOWER = false, int G = 4, bool TRI = false, class PH = const double*, class PR = const double*,
+          class PA = const uint8_t*, class PD = double*>
+__device__ __forceinline__ void gj_solve_regs(int lane, PH H, int ldh, PR rhs, PA act, int p, double reg_rel, PD dv) {
   const bool live = lane < p;
   const bool my_act = live && act[lane] != 0;
-  double diag0 = (live && !my_act) ? H[lane * ldh + lane] : 0.0;
+  double diag0 = (live && !my_act) ? H[TRI ? tri_idx((uint32_t)lane, (uint32_t)lane) : (uint32_t)(lane * ldh + lane)] : 0.0;
   const double maxdiag = wave_max_f64(diag0);
   const double reg = reg_rel * maxdiag;
   double h[PM + 1];  // h[PM]: right-hand side
@@ -139,7 +139,7 @@ __device__ __forceinline__ void gj_solve_regs(int lane, const double* H, int ldh
   for (int j = 0; j < PM; ++j) {
     double v = 0.0;
     if (j < p) {
-      if (live && !my_act) v = (LOWER && j > lane) ? H[j * ldh + lane] : H[lane * ldh + j];
+      if (live && !my_act) v = TRI ? H[tri_idx((uint32_t)lane, (uint32_t)j)] : (LOWER && j > lane) ? H[j * ldh + lane] : H[lane * ldh + j];
       if (j == lane) v = my_act ? 1.0 : v + reg;
     } else if (j == lane) v = 1.0;  // rows beyond p: identity
     h[j] = v;
@@ -360,6 +360,26 @@ __device__ __forceinline__ void gj_solve_small(int lane, const double* H, int ld
     else if (p <= 56) gj_solve_regs_small<56, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
     else gj_solve_regs_small<64, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
   }
+}
+
+// The batched form for the multi-wave contexts with the 256-register budget (wave 0 solves systems of up to 64 rows: the
+// TSP-50 class), as a REAL call: inlined into those kernels the 57-column row would spill, the one-column-at-a-time form
+// above (which they used until round 4) pays the scalar-write hazard per column: 25 cycles against 15.
+template <bool TRI>
+CAVE_NOINLINE __device__ void gj_solve_wide_call(int lane, const double* H_, int ldh, const double* g_, const uint8_t* act_, int p,
+                                                 double reg_rel, double* dv_) {
+  // (everything lives in LDS on this path: typed, so that the call reads ds_* rather than flat_*)
+  const auto H = space_cast<3>(H_);
+  const auto g = space_cast<3>(g_);
+  const auto act = space_cast<3>(act_);
+  const auto dv = space_cast<3>(dv_);
+  if (p <= 16) gj_solve_regs<16, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 24) gj_solve_regs<24, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 32) gj_solve_regs<32, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 40) gj_solve_regs<40, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 48) gj_solve_regs<48, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else if (p <= 56) gj_solve_regs<56, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
+  else gj_solve_regs<64, false, 4, TRI>(lane, H, ldh, g, act, p, reg_rel, dv);
 }
 
 // size-specialised dispatch; PLIM bounds the register footprint (2*PM + 2 VGPRs for the row)
