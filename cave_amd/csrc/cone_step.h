@@ -214,14 +214,38 @@ CAVE_HD void run_lite_instance(SC& sc, unsigned char* smem, uint32_t lds_bytes, 
   ar.init(smem, lds_bytes);
   int32_t st = ST_OK;
   int iters = 0;
-  const int64_t slot = P.ids ? P.ids[b] : b;
-  const bool in_range = slot >= 0 && slot < S.n;
-  const int32_t* hdr = S.hdr + (in_range ? slot : 0) * kLiteHdr;
-  const int32_t state = in_range ? hdr[0] : 0;
-  const int p = hdr[1], nF = hdr[3], n_valid = hdr[4], cmax = hdr[5], chn8 = hdr[6];
+  const int64_t slot_raw = P.ids ? P.ids[b] : b;
+  const bool in_range = slot_raw >= 0 && slot_raw < S.n;
+  const int64_t slot = in_range ? slot_raw : 0;
   const int mode = P.mode;
   const bool need_avg = (mode == MODE_INNER || mode == MODE_HEURISTIC || mode == MODE_AVG);
   const bool need_proj = (mode == MODE_PROJECT || mode == MODE_EXACT || mode == MODE_INNER);
+  // ---- prologue: EVERY global load of the instance in one memory round trip -- the header words beside the arrays
+  // (nothing below depends on them: a slot's arrays have fixed extents, what a cone does not use is loaded and dropped);
+  // until round 4 the header came first and the arrays a latency later (~2 us of a 70 us instance)
+  constexpr int KC = (kLiteMaxD + 63) / 64;  // coordinates per lane
+  float yv[KC], av[KC];
+  uint4 ev[KC];
+  uint8_t uv[KC];
+#pragma unroll
+  for (int s = 0; s < KC; ++s) {
+    const int k = lane + 64 * s, kc = k < d ? k : d - 1;
+    yv[s] = P.pred ? P.pred[b * d + kc] : 0.f;
+    uv[s] = S.usign[slot * d + kc];
+    av[s] = need_avg ? S.avg[slot * d + kc] : 0.f;
+    ev[s] = need_proj ? reinterpret_cast<const uint4*>(S.ell + slot * 4 * (int64_t)d)[kc] : make_uint4(0, 0, 0, 0);
+  }
+  uint4 cv[kLiteMaxChunk / 8];
+#pragma unroll
+  for (int g8 = 0; g8 < kLiteMaxChunk / 8; ++g8)
+    cv[g8] = need_proj ? reinterpret_cast<const uint4*>(S.csr16 + slot * (int64_t)kLiteCsrWords)[g8 * 64 + lane] : make_uint4(0, 0, 0, 0);
+  const uint32_t mp_raw = (need_proj && lane <= kLiteMaxRows) ? S.rowptr[slot * (kLiteMaxRows + 1) + lane] : 0u;
+  const uint8_t rl_raw = (need_proj && lane < kLiteMaxRows) ? S.rl[slot * kLiteMaxRows + lane] : (uint8_t)0;
+  const int32_t* hdr = S.hdr + slot * kLiteHdr;
+  const int32_t hv = lane < kLiteHdr ? hdr[lane] : 0;  // (one load; the words are handed out below)
+  const int32_t state = in_range ? __builtin_amdgcn_readlane(hv, 0) : 0;
+  const int p = __builtin_amdgcn_readlane(hv, 1), nF = __builtin_amdgcn_readlane(hv, 3), n_valid = __builtin_amdgcn_readlane(hv, 4);
+  const int cmax = __builtin_amdgcn_readlane(hv, 5), chn8 = __builtin_amdgcn_readlane(hv, 6);
   if (!in_range) st = ST_BAD_INPUT;
   else if (state != 1 || p < 0 || p > kLiteMaxRows || chn8 > kLiteMaxChunk || mode == MODE_IPM) st = ST_TOO_LARGE;
   else {
@@ -255,26 +279,9 @@ CAVE_HD void run_lite_instance(SC& sc, unsigned char* smem, uint32_t lds_bytes, 
     w.act = ar.get<uint8_t>(pp);
     if (ar.ovf || !ell || !csr16) st = ST_TOO_LARGE;
     else {
-      // ---- prologue: every global load first (U per lane and array), then the LDS stores
-      constexpr int KC = (kLiteMaxD + 63) / 64;  // coordinates per lane
-      float yv[KC], av[KC];
-      uint4 ev[KC];
-      uint8_t uv[KC];
-#pragma unroll
-      for (int s = 0; s < KC; ++s) {
-        const int k = lane + 64 * s, kc = k < d ? k : d - 1;
-        yv[s] = P.pred ? P.pred[b * d + kc] : 0.f;
-        uv[s] = S.usign[slot * d + kc];
-        av[s] = need_avg ? S.avg[slot * d + kc] : 0.f;
-        ev[s] = need_proj && p > 0 ? reinterpret_cast<const uint4*>(S.ell + slot * 4 * (int64_t)d)[kc] : make_uint4(0, 0, 0, 0);
-      }
-      uint4 cv[kLiteMaxChunk / 8];
-#pragma unroll
-      for (int g8 = 0; g8 < kLiteMaxChunk / 8; ++g8)
-        cv[g8] = (need_proj && g8 * 8 < chn8) ? reinterpret_cast<const uint4*>(S.csr16 + slot * (int64_t)kLiteCsrWords)[g8 * 64 + lane]
-                                             : make_uint4(0, 0, 0, 0);
-      const uint32_t mp = (need_proj && lane <= p) ? S.rowptr[slot * (kLiteMaxRows + 1) + lane] : 0u;
-      const uint8_t rlv = (need_proj && lane < p) ? S.rl[slot * kLiteMaxRows + lane] : (uint8_t)0;
+      // ---- the LDS stores of what the prologue loaded
+      const uint32_t mp = lane <= p ? mp_raw : 0u;
+      const uint8_t rlv = lane < p ? rl_raw : (uint8_t)0;
 #pragma unroll
       for (int s = 0; s < KC; ++s) {
         const int k = lane + 64 * s;
