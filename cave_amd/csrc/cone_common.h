@@ -222,6 +222,7 @@ struct SolveView {
   const uint8_t* usign;   // [d]  bit0: +e_k row present, bit1: -e_k row present
   int nlong;              // reduced rows with more than kLongRow entries ...
   const uint32_t* longrow;  // ... and their indices
+  double gcol_bound = 0.0;  // > 0: g = -M rc is summed COLUMN-wise in fixed point (cone_dense.h dense_gradient): (longest row) x (largest |entry|)
   int nteam = 0;            // of those, rows with more than kTeamRow entries (shared by the waves in the streamed gradient) ...
   const uint32_t* teamrow = nullptr;  // ... and their indices
   bool csc_far = false;   // "diet" layout (TSP-50 class: cone_instance.h run_packed_instance): cvar points into the packed

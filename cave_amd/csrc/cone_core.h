@@ -428,6 +428,7 @@ CAVE_HD double refresh_clipped(C& c, const SolveView& v, const double* r, double
 // g = -M rc.  Rows are shared by TEAM adjacent lanes (fixed reduction tree); rows longer than
 // kLongRow entries are summed by one whole wave each.
 
+template <class C, bool PM1> CAVE_NOINLINE void dense_gradient(C& c_, const SolveView& v_, const double* rc, double* g_);
 template <class C, bool PM1> CAVE_HD void gradient_long_rows_streamed(C& c, const SolveView& v, const double* rc, double* g);
 template <class C, bool PM1> CAVE_NOINLINE void gradient_short_rows_streamed(C& c, const SolveView& v, const double* rc, double* g);
 
@@ -436,6 +437,10 @@ CAVE_HD void gradient(C& c, const SolveView& v, const double* rc, double* g) {
   constexpr int TEAM = C::TEAM;
   constexpr int RPP = C::NT / TEAM;  // rows per pass
   if constexpr (STREAMED && C::WL > 1 && TEAM == 4) {  // large-cone path: the cone is in global memory
+    if (v.gcol_bound > 0.0) {  // dense reduced systems (TSP-100 class): column-wise, fixed point (cone_dense.h)
+      dense_gradient<C, PM1>(c, v, rc, g);
+      return;
+    }
     gradient_short_rows_streamed<C, PM1>(c, v, rc, g);
     gradient_long_rows_streamed<C, PM1>(c, v, rc, g);
     c.sync();

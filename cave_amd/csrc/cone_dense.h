@@ -166,6 +166,72 @@ CAVE_NOINLINE void dense_hessian(C& c_, const SolveView& v_, W weight, const Den
   c.sync();
 }
 
+// g = -M rc summed COLUMN-wise (round 4).  The row-wise form gathers an 8-byte operand per entry from a line of its own
+// -- the per-CU L1 serves about a line per cycle, 130 k gathers per pass of a TSP-100 cone: 78 us, the largest cut row on
+// one wave -- while a pass over the columns reads rc and the column entries coalesced (the Hessian and M^T theta passes
+// above take 25 - 65 us).  The sums go to g itself, in LDS, as 64-bit FIXED POINT (integer adds are associative: any
+// arrival order gives the same bits), scaled by (largest |rc_k|) x (longest row) x (largest |entry|) to 2^61: an add
+// rounds to 2^-61 of that bound, the sum of a 4 700-entry row to ~1e-12 of the largest residual -- the size of the
+// gradient test's rounding floor.  g must live in LDS (p <= 128 on this path).
+template <class C, bool PM1>
+CAVE_NOINLINE void dense_gradient(C& c_, const SolveView& v_, const double* rc, double* g_) {
+  CtxLocal<C> cl(c_);
+  C& c = cl.c;
+  const SolveView v = v_;
+  constexpr int NT = C::NT;
+  const int p = v.p, d = v.d;
+  const auto cptr = space_cast<1>(v.cptr);
+  auto Gq = space_cast<3>(reinterpret_cast<long long*>(g_));
+  auto Gd = space_cast<3>(g_);
+  double rmax = 0.0;
+  strided_batched<8, NT>(c.tid(), d, [&](int k) { return rc[k]; }, [&](int, double x) { rmax = fmax(rmax, fabs(x)); });
+  for (int i = c.tid(); i < p; i += NT) Gq[i] = 0;
+  rmax = c.reduce_max(rmax);  // (a barrier: the zeroes are in place)
+  const double sc = fixed_scale(rmax, v.gcol_bound), inv = 1.0 / sc;
+  constexpr int G = 4, E = 8;
+  const uint32_t last = cptr[d] > 0u ? cptr[d] - 1u : 0u;
+  for (int kb = c.tid(); kb < d; kb += G * NT) {
+    uint32_t lo[G], cnt[G], a[G][E];
+    double rk[G], x[G][E];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int k = kb + u * NT;
+      const bool in = k < d;
+      const int kc = in ? k : d - 1;
+      lo[u] = cptr[kc];
+      cnt[u] = in ? cptr[kc + 1] - lo[u] : 0u;
+      rk[u] = rc[kc];
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t ee = lo[u] + (uint32_t)e < last ? lo[u] + (uint32_t)e : last;  // clamped: loads are unconditional
+        csc_entry<PM1, 1>(v, ee, a[u][e], x[u][e]);
+      }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (rk[u] == 0.0 || cnt[u] == 0u) continue;
+      const double t = -rk[u] * sc;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if ((uint32_t)e < cnt[u]) c.atomic_add_i64_lds(Gq + a[u][e], (long long)llrint(x[u][e] * t));
+      for (uint32_t e = (uint32_t)E; e < cnt[u]; ++e) {  // columns with more than E entries (edges inside several cuts)
+        uint32_t a1;
+        double v1;
+        csc_entry<PM1, 1>(v, lo[u] + e, a1, v1);
+        c.atomic_add_i64_lds(Gq + a1, (long long)llrint(v1 * t));
+      }
+    }
+  }
+  c.sync();
+  for (int i = c.tid(); i < p; i += NT) {
+    const long long q = Gq[i];
+    Gd[i] = (double)q * inv;
+  }
+  c.sync();
+}
+
 // Partial LDL^T: pivots 0 .. nF-1 of A + reg I (reg = reg_rel * largest diagonal entry), the right-hand side z
 // eliminated alongside.  Afterwards rows < nF hold the rows of U (dinv: reciprocal pivots), rows >= nF the Schur
 // complement, z[nF ..] the reduced right-hand side.  Four pivots per step: wave 0 eliminates the four pivot rows

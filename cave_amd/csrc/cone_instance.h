@@ -184,6 +184,8 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     w.warm = warm_on ? warm_theta : nullptr;
     bool rb_wanted = false;
     (void)rb_wanted;
+    double gcol_bound = 0.0;  // (longest row) x (largest |entry|) of the reduced cone: scale of the column-wise gradient
+    (void)gcol_bound;
     if constexpr (LARGE) {
       const int bw = band_halfwidth(c, v);
       const uint32_t ld = (uint32_t)bw + 1u;
@@ -212,6 +214,7 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
         ml = c.reduce_max(ml);
         w.hscale = fixed_scale(vm, vm * ml);
         w.hinv = 1.0 / w.hscale;
+        gcol_bound = vm * ml;
       }
       if (hot && p >= 1 && dense_shape(p, bw)) {
         uint32_t cnt = 0;
@@ -392,6 +395,10 @@ CAVE_HD int32_t solve_and_finish(C& c, Arena& ar, Arena* hot, const SolveView& v
     vv.nlong = (int)c.compact_nonzero_u8(lflag, p, llist);
     vv.longrow = llist;
     c.sync();
+    if constexpr (LARGE) {
+      // dense reduced systems with g in LDS: the gradient is summed column-wise in fixed point (cone_dense.h dense_gradient)
+      if (w.dn.on && hot && hot->owns(w.g) && C::WL > 1 && mode != MODE_IPM) vv.gcol_bound = gcol_bound;
+    }
     if constexpr (LARGE) {  // (the streamed gradient shares very long rows between the waves)
       uint32_t* tlist = ar.get<uint32_t>(pp);
       if (ar.ovf) return ST_TOO_LARGE;
