@@ -188,7 +188,7 @@ CAVE_NOINLINE void dense_gradient(C& c_, const SolveView& v_, const double* rc, 
   for (int i = c.tid(); i < p; i += NT) Gq[i] = 0;
   rmax = c.reduce_max(rmax);  // (a barrier: the zeroes are in place)
   const double sc = fixed_scale(rmax, v.gcol_bound), inv = 1.0 / sc;
-  constexpr int G = 4, E = 8;
+  constexpr int G = 4, E = 4;
   const uint32_t last = cptr[d] > 0u ? cptr[d] - 1u : 0u;
   for (int kb = c.tid(); kb < d; kb += G * NT) {
     uint32_t lo[G], cnt[G], a[G][E];
