@@ -341,6 +341,49 @@ CAVE_NOINLINE void dense_factor(C& c_, const DenseWork& dw_, int p, double reg_r
           p1[a] = scP[a * pc + t0 + 1];
           zq[a] = z[k0 + a < p ? k0 + a : p - 1];
         }
+#if defined(__HIPCC__) && !defined(CAVE_SIMT_EMUL) && !defined(CAVE_DENSE_NO_MFMA)
+        // Rank-4 update of the trailing triangle on the matrix cores (round 4): v_mfma_f64_16x16x4_f64 takes a 16 x 16
+        // tile C, the 16 x 4 block -Q^T of the multipliers and the 4 x 16 block P of the pivot rows, one instruction per
+        // tile.  On MI355X the f64 MFMA has the VALU's flop rate -- the gain is in the LDS: a lane reads its two operands
+        // and four entries of C and writes those four back (5 KB per tile), where the two-columns-per-lane form below
+        // read four broadcast multipliers per ROW and lane, half of the lanes left of the diagonal idling (3.3x the
+        // traffic; the update was 62 % of the factorisation and LDS-bound with two workgroups per compute unit).
+        // Tiles (I <= J) of the trailing square go round the waves; A[l & 15][k = l >> 4], B[k = l >> 4][l & 15],
+        // C: column l & 15, rows (l >> 4) + 4 i (the f64 layout: cdna_hip_programming.md).
+        {
+          typedef double v4d __attribute__((ext_vector_type(4)));
+          const int nt = p - cb, T = (nt + 15) >> 4, ntile = T * (T + 1) / 2;
+          const int lr = lane & 15, lg = lane >> 4;
+          (void)c0; (void)t0; (void)p0; (void)p1;
+          for (int ti = wave; ti < ntile; ti += NWV) {
+            int I = 0, rem = ti;
+            while (rem >= T - I) { rem -= T - I; ++I; }  // (wave-uniform: tile ti of the upper triangle, row-major)
+            const int r0 = cb + 16 * I, cc0 = cb + 16 * (I + rem);
+            const int ar = r0 + lr, bc = cc0 + lr;
+            double av = -scQ[lg * pc + ((ar < p ? ar : p - 1) - k0)];  // (clamped, unconditional; rows / columns past
+            double bv = scP[lg * pc + ((bc < p ? bc : p - 1) - k0)];    //  the matrix contribute zeros)
+            av = ar < p ? av : 0.0;
+            bv = bc < p ? bv : 0.0;
+            v4d acc;
+            int o[4];
+            bool in[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = r0 + lg + 4 * i;
+              in[i] = row < p && bc < p && bc >= row;
+              o[i] = in[i] ? fold_base(p, row) + (bc - row) : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = A[o[i]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = in[i] ? acc[i] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (in[i]) A[o[i]] = acc[i];
+          }
+        }
+#else
         // RB trailing rows per pass, every load of the pass before its first store: rows are independent, and one
         // row at a time each iteration waited out its own LDS round trips (12 k cycles per block step on TSP-100)
         constexpr int RB = 4;
@@ -374,6 +417,7 @@ CAVE_NOINLINE void dense_factor(C& c_, const DenseWork& dw_, int p, double reg_r
             if (in1[j]) A[o[j] + 1] = t1v[j];
           }
         }
+#endif
         for (int r = cb + tid; r < p; r += NT) {  // the right-hand side below the block
           double zz = z[r];
 #pragma unroll
